@@ -1,0 +1,129 @@
+// rrtmg_abi.hip -- extern "C" surface of librrtmg_hip.so (declared in include/rrtmg_hip.h).
+#include <dlfcn.h>
+
+#include <cstring>
+#include <mutex>
+
+#include "rrtmg_ctx.h"
+
+namespace rrtmg {
+
+const char *status_message(int code) {
+  switch (code) {
+    case RRTMG_OK: return "ok";
+    case RRTMG_ERR_HIP: return "HIP runtime error";
+    case RRTMG_ERR_NOT_INITIALISED: return "not initialised";
+    case RRTMG_ERR_TABLES: return "table blob error";
+    case RRTMG_ERR_ARG: return "bad argument";
+    case RRTMG_ERR_PARTIAL_CLOUD: return "PARTIAL CLOUD NOT ALLOWED";
+    case RRTMG_ERR_ICE_RADIUS: return "ICE RADIUS OUT OF BOUNDS";
+    case RRTMG_ERR_LIQ_RADIUS: return "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS";
+    case RRTMG_ERR_CLOUD_OPTICS: return "CLOUD OPTICAL PROPERTY OUT OF RANGE";
+    case RRTMG_ERR_KISS_PRESSURE: return "MCICA_SUBCOL: KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS.";
+    case RRTMG_ERR_ICLD: return "MCICA_SUBCOL: INVALID ICLD";
+    case RRTMG_ERR_UNSUPPORTED: return "option not supported by this build";
+    default: return "unknown error";
+  }
+}
+
+int ctx_prepare_device(rrtmg_ctx *ctx) {
+  RRTMG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (!ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (!ctx->err_dev) RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
+  return RRTMG_OK;
+}
+
+std::string default_blob_path(const char *which) {
+  if (const char *env = getenv(strcmp(which, "sw") == 0 ? "RRTMG_HIP_SW_DATA" : "RRTMG_HIP_LW_DATA")) return env;
+  Dl_info info;
+  std::string dir = ".";
+  if (dladdr((void *)&default_blob_path, &info) && info.dli_fname) {
+    std::string p(info.dli_fname);
+    size_t k = p.rfind('/');
+    dir = (k == std::string::npos) ? "." : p.substr(0, k);
+  }
+  return dir + "/../data/rrtmg_" + which + "_data.bin";
+}
+
+}  // namespace rrtmg
+
+using namespace rrtmg;
+
+extern "C" {
+
+const char *rrtmg_hip_version(void) { return "rrtmg-hip 0.1 (gfx950)"; }
+
+int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
+  if (!out) return RRTMG_ERR_ARG;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  rrtmg_ctx *c = new rrtmg_ctx();
+  c->device = device_ordinal;
+  *out = c;
+  if (e != hipSuccess || n <= 0)
+    return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));
+  if (device_ordinal < 0 || device_ordinal >= n) return c->fail(RRTMG_ERR_ARG, "device ordinal %d out of range (%d devices)", device_ordinal, n);
+  return ctx_prepare_device(c);
+}
+
+void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  for (auto &kv : ctx->bufs)
+    if (kv.second.p) (void)hipFree(kv.second.p);
+  if (ctx->sw_tab_dev) (void)hipFree(ctx->sw_tab_dev);
+  if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
+  if (ctx->err_dev) (void)hipFree(ctx->err_dev);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  rrtmg::free_sw_desc(ctx);
+  rrtmg::free_lw_desc(ctx);
+  delete ctx;
+}
+
+const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+void *rrtmg_hip_stream(rrtmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTMG_OK;
+}
+
+int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz, double clight,
+                            double avogad, double alosmt, double gascon, double sbcnst, double secdy) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  Constants &k = ctx->k;
+  k.pi = pi; k.grav = grav; k.planck = planck; k.boltz = boltz; k.clight = clight; k.avogad = avogad;
+  k.alosmt = alosmt; k.gascon = gascon; k.sbcnst = sbcnst; k.secdy = secdy;
+  k.radcn1 = 2. * planck * clight * clight * 1.e-07;
+  k.radcn2 = planck * clight / boltz;
+  ctx->have_constants = true;
+  return RRTMG_OK;
+}
+
+int rrtmg_hip_sw_init(rrtmg_ctx *ctx, double cpdair, const char *blob_path) { return ctx ? sw_init_impl(ctx, cpdair, blob_path) : RRTMG_ERR_ARG; }
+int rrtmg_hip_lw_init(rrtmg_ctx *ctx, double cpdair, const char *blob_path) { return ctx ? lw_init_impl(ctx, cpdair, blob_path) : RRTMG_ERR_ARG; }
+int rrtmg_hip_lw_tables_synthetic(const rrtmg_ctx *ctx) { return ctx && ctx->lw_ts.synthetic ? 1 : 0; }
+
+long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long capacity) {
+  if (!ctx || !name) return -1;
+  const TableSet &ts = (strncmp(name, "sw/", 3) == 0) ? ctx->sw_ts : ctx->lw_ts;
+  auto it = ts.reg.find(name);
+  if (it == ts.reg.end()) return -1;
+  const long n = it->second.n;
+  if (out) {
+    if (capacity < n) return -2;
+    memcpy(out, ts.flat.data() + it->second.off, (size_t)n * sizeof(double));
+  }
+  return n;
+}
+
+int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a) { return ctx ? sw_fluxes_impl(ctx, a) : RRTMG_ERR_ARG; }
+int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a) { return ctx ? lw_fluxes_impl(ctx, a) : RRTMG_ERR_ARG; }
+
+int rrtmg_hip_mcica_mask(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
+                         const double *play, const double *cldfrac, double *cldfmcl) {
+  return ctx ? mcica_mask_impl(ctx, which, ncol, nlay, icld, permuteseed, irng, play, cldfrac, cldfmcl) : RRTMG_ERR_ARG;
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// rrtmg_ctx.h -- private context of librrtmg_hip.so (one per GPU / component instance).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/rrtmg_hip.h"
+#include "rrtmg_common.h"
+#include "rrtmg_tables.h"
+
+namespace rrtmg {
+
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+};
+
+}  // namespace rrtmg
+
+struct rrtmg_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int status = 0;
+  rrtmg::Constants k{};
+  bool have_constants = false;
+  // tables
+  rrtmg::TableSet sw_ts, lw_ts;
+  bool sw_ready = false, lw_ready = false;
+  double *sw_tab_dev = nullptr, *lw_tab_dev = nullptr;
+  void *sw_desc = nullptr, *lw_desc = nullptr;   // SwTab / LwTab (host copies, owned)
+  // grow-only device work buffers, by name
+  std::map<std::string, rrtmg::DevBuf> bufs;
+  int *err_dev = nullptr;
+
+  int fail(int code, const char *fmt, ...) {
+    char tmp[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(tmp, sizeof tmp, fmt, ap);
+    va_end(ap);
+    err = tmp;
+    status = code;
+    return code;
+  }
+  // returns nullptr on allocation failure (err set)
+  void *buf(const std::string &name, size_t bytes) {
+    rrtmg::DevBuf &b = bufs[name];
+    if (b.cap >= bytes && b.p) return b.p;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes < 256 ? 256 : bytes;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+      fail(RRTMG_ERR_HIP, "hipMalloc(%zu bytes) for '%s' failed: %s", want, name.c_str(), hipGetErrorString(e));
+      b.p = nullptr;
+      return nullptr;
+    }
+    b.cap = want;
+    return b.p;
+  }
+};
+
+#define RRTMG_HIP_CHECK(ctx, call)                                                                     \
+  do {                                                                                                 \
+    hipError_t e__ = (call);                                                                           \
+    if (e__ != hipSuccess)                                                                             \
+      return (ctx)->fail(RRTMG_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__), __FILE__, __LINE__); \
+  } while (0)
+
+namespace rrtmg {
+const char *status_message(int code);
+int ctx_prepare_device(rrtmg_ctx *ctx);   // hipSetDevice + lazy stream / error-flag creation
+std::string default_blob_path(const char *which);
+void free_sw_desc(rrtmg_ctx *ctx);
+void free_lw_desc(rrtmg_ctx *ctx);
+int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a);
+int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a);
+int sw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob);
+int lw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob);
+int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
+                    const double *play, const double *cldfrac, double *cldfmcl);
+// Mersenne-twister CDF stream of the reference (mcica_random_numbers.f90:77-302) -> bit mask on host
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
+}  // namespace rrtmg

@@ -1,0 +1,311 @@
+// rrtmg_sw.hip -- shortwave kernels and launch sequence (gfx950).
+//
+// Launch sequence of one rrtmg_hip_sw_fluxes call (all on ctx->stream):
+//   sw_prep_kernel      <<<ncol/64>>>            inatm_sw + setcoef_sw per column
+//   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
+//   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
+//   sw_kiss_kernel / mask upload (mcica)         sub-column cloud mask
+//   sw_solve_kernel<B>  14 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
+//   sw_finish_kernel    <<<ncol/64>>>            g-point sum, heating rates
+#include "rrtmg_ctx.h"
+#include "rrtmg_sw_device.h"
+#include "rrtmg_sw_host.h"
+
+namespace rrtmg {
+
+__global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) sw_prep_column(d, T, col);
+}
+
+__global__ void __launch_bounds__(64) sw_cloud_kernel(SwDev d, SwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int lay = blockIdx.y;
+  if (col < d.ncol) sw_cloud_layer(d, T, col, lay);
+}
+
+// ECMWF aerosol mixing (iaer = 6), rrtmg_sw_rad.nomcica.f90:693-727 -> per-band tau/ssa/asm
+__global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const double *ecaer, double *ta, double *om, double *as) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int lay = blockIdx.y;
+  if (col >= d.ncol) return;
+  const int L = d.nlay, N = d.ncol;
+  const double *t = T.t;
+  for (int ib = 0; ib < kSwNBand; ++ib) {
+    double ztaua = 0.0, zasya = 0.0, zomga = 0.0;
+    for (int ia = 0; ia < 6; ++ia) {
+      const double e = ecaer[((long)ia * L + lay) * N + col];
+      const double rt = t[T.rsrtaua + ib + kSwNBand * ia], rp = t[T.rsrpiza + ib + kSwNBand * ia], ra = t[T.rsrasya + ib + kSwNBand * ia];
+      ztaua = ztaua + rt * e;
+      zomga = zomga + rt * e * rp;
+      zasya = zasya + rt * e * rp * ra;
+    }
+    if (ztaua == 0.0) {
+      ztaua = 0.0; zasya = 0.0; zomga = 1.0;
+    } else {
+      if (zomga != 0.0) zasya = zasya / zomga;
+      if (ztaua != 0.0) zomga = zomga / ztaua;
+    }
+    const long o = ((long)ib * L + lay) * N + col;
+    ta[o] = ztaua; om[o] = zomga; as[o] = zasya;
+  }
+}
+
+__global__ void __launch_bounds__(64) kiss_mask_kernel(int ncol, int nlay, int nsub, int icld, int seed, const double *play,
+                                                       const double *cldfr, uint64_t *mask, int nw, int *err) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < ncol) kiss_mask_column(ncol, nlay, nsub, icld, seed, play, cldfr, mask, nw, err, col);
+}
+
+// externally supplied cldfmcl [lay][col][nsub] (0/1 doubles) -> bit mask
+__global__ void __launch_bounds__(64) mask_from_cldfmcl_kernel(int ncol, int nlay, int nsub, const double *cldfmcl, uint64_t *mask, int nw) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (col >= ncol) return;
+  for (int w = 0; w < nw; ++w) {
+    uint64_t m = 0;
+    for (int l = w * 64; l < nlay && l < (w + 1) * 64; ++l)
+      if (cldfmcl[((long)l * ncol + col) * nsub + g] > 1.e-12) m |= 1ull << (l & 63);
+    mask[((long)g * nw + w) * ncol + col] = m;
+  }
+}
+
+// bit mask -> cldfmcl doubles (for the stand-alone sub-column generator entry point)
+__global__ void __launch_bounds__(64) cldfmcl_from_mask_kernel(int ncol, int nlay, int nsub, const uint64_t *mask, int nw, double *cldfmcl) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  const int g = blockIdx.y;
+  if (col >= ncol) return;
+  for (int l = 0; l < nlay; ++l) {
+    const uint64_t m = mask[((long)g * nw + (l >> 6)) * ncol + col];
+    cldfmcl[((long)l * ncol + col) * nsub + g] = ((m >> (l & 63)) & 1ull) ? 1.0 : 0.0;
+  }
+}
+
+template <int BAND>
+__global__ void __launch_bounds__(64) sw_solve_kernel(SwDev d, SwTab T) {
+  const int ng = T.b[BAND - 16].ng;
+  const int tile = blockIdx.x / ng, ig = blockIdx.x - tile * ng;
+  const int col = tile * 64 + threadIdx.x;
+  if (col >= d.ncol) return;
+  double *scr = d.scratch + (long)blockIdx.x * F_NTOT * d.nlay * 64 + threadIdx.x;
+  sw_solve_thread<BAND>(d, T, col, ig, scr, 64);
+}
+
+__global__ void __launch_bounds__(64) sw_finish_kernel(SwDev d, SwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) sw_finish_column(d, T, col);
+}
+
+template <int BAND>
+static void launch_solve(const SwDev &d, const SwTab &T, hipStream_t s) {
+  const int ntile = (d.ncol + 63) / 64;
+  const int ng = T.b[BAND - 16].ng;
+  hipLaunchKernelGGL(sw_solve_kernel<BAND>, dim3(ntile * ng), dim3(64), 0, s, d, T);
+}
+
+void free_sw_desc(rrtmg_ctx *ctx) {
+  delete (SwTab *)ctx->sw_desc;
+  ctx->sw_desc = nullptr;
+}
+
+// stand-alone sub-column generator (host pointers): mask on the device (kissvec) or host (MT)
+int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
+                    const double *play, const double *cldfrac, double *cldfmcl) {
+  if (ncol <= 0 || nlay <= 0 || !play || !cldfrac || !cldfmcl) return ctx->fail(RRTMG_ERR_ARG, "mcica_mask: bad argument");
+  if (icld < 0 || icld > 3) return ctx->fail(RRTMG_ERR_ICLD, "%s", status_message(RRTMG_ERR_ICLD));
+  const int nsub = which == 0 ? kSwNGpt : 140;
+  const int nw = (nlay + 63) / 64;
+  const size_t nl = (size_t)ncol * nlay;
+  if (icld == 0) return RRTMG_OK;   // mcica_subcol_*: "if (icld.eq.0) return" -- outputs untouched
+  if (irng != 0) {
+    std::vector<uint64_t> hm;
+    mt_mask_host(ncol, nlay, nsub, icld, permuteseed, cldfrac, hm, nw);
+    for (int l = 0; l < nlay; ++l)
+      for (int c = 0; c < ncol; ++c)
+        for (int g = 0; g < nsub; ++g)
+          cldfmcl[((size_t)l * ncol + c) * nsub + g] = ((hm[((size_t)g * nw + (l >> 6)) * ncol + c] >> (l & 63)) & 1ull) ? 1.0 : 0.0;
+    return RRTMG_OK;
+  }
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  double *dp = (double *)ctx->buf("mm.play", nl * 8), *dc = (double *)ctx->buf("mm.cld", nl * 8);
+  double *dm = (double *)ctx->buf("mm.out", nl * nsub * 8);
+  uint64_t *mk = (uint64_t *)ctx->buf("mm.mask", (size_t)nsub * nw * ncol * 8);
+  if (!dp || !dc || !dm || !mk) return ctx->status;
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(dp, play, nl * 8, hipMemcpyHostToDevice, s));
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(dc, cldfrac, nl * 8, hipMemcpyHostToDevice, s));
+  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(ctx->err_dev, 0, sizeof(int), s));
+  const int ntile = (ncol + 63) / 64;
+  hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile), dim3(64), 0, s, ncol, nlay, nsub, icld, permuteseed, dp, dc, mk, nw, ctx->err_dev);
+  hipLaunchKernelGGL(cldfmcl_from_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, nsub, mk, nw, dm);
+  int herr = 0;
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, ctx->err_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cldfmcl, dm, nl * nsub * 8, hipMemcpyDeviceToHost, s));
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (herr) return ctx->fail(herr, "mcica_mask: %s", status_message(herr));
+  return RRTMG_OK;
+}
+
+int sw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob_path) {
+  if (!ctx->have_constants) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "set_constants must be called before sw_init");
+  std::string path = blob_path ? std::string(blob_path) : default_blob_path("sw");
+  Blob blob;
+  std::string err;
+  if (!blob.load(path, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  ctx->sw_ts = TableSet();
+  if (!build_tables(blob, "sw", cpdair, ctx->k.grav, ctx->k.secdy, ctx->sw_ts, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  SwTab *T = ctx->sw_desc ? (SwTab *)ctx->sw_desc : new SwTab();
+  ctx->sw_desc = T;
+  if (!build_sw_tab(ctx->sw_ts, *T, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  if (ctx->sw_tab_dev) (void)hipFree(ctx->sw_tab_dev);
+  ctx->sw_tab_dev = nullptr;
+  RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->sw_tab_dev, ctx->sw_ts.flat.size() * sizeof(double)));
+  RRTMG_HIP_CHECK(ctx, hipMemcpy(ctx->sw_tab_dev, ctx->sw_ts.flat.data(), ctx->sw_ts.flat.size() * sizeof(double), hipMemcpyHostToDevice));
+  T->t = ctx->sw_tab_dev;
+  ctx->sw_ready = true;
+  return RRTMG_OK;
+}
+
+int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
+  if (!ctx->sw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_sw_init has not been called");
+  if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
+  if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const int N = a->ncol, L = a->nlay;
+  const size_t nl = (size_t)N * L, nl1 = (size_t)N * (L + 1);
+  const SwTab &T = *(SwTab *)ctx->sw_desc;
+  SwDev d{};
+  d.ncol = N; d.nlay = L;
+  d.icld = a->icld; d.iaer = a->iaer;
+  if (d.icld < 0 || d.icld > 3) d.icld = 2;                 // rrtmg_sw_rad.nomcica.f90:563
+  if (d.iaer != 0 && d.iaer != 6 && d.iaer != 10) d.iaer = 0;
+  d.inflag = a->inflgsw; d.iceflag = a->iceflgsw; d.liqflag = a->liqflgsw; d.mcica = a->mcica ? 1 : 0;
+  d.k = ctx->k;
+  std::string err;
+  rc = sw_scalar_setup(d, a->isolvar, a->adjes, a->dyofyr, a->scon, a->bndsolvar, a->indsolvar, err);
+  if (rc) return ctx->fail(rc, "%s", err.c_str());
+  if (d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "inflgsw=1 has no shortwave implementation in RRTMG_SW (cldprop_sw handles 0 and 2)");
+
+  // ---- inputs -----------------------------------------------------------------------------
+  bool ok = true;
+  auto in = [&](const double *p, size_t n, const char *name, bool required) -> const double * {
+    if (!p) {
+      if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
+      return nullptr;
+    }
+    if (a->memspace == 1) return p;
+    double *dp = (double *)ctx->buf(std::string("sw.in.") + name, n * sizeof(double));
+    if (!dp) { ok = false; return nullptr; }
+    if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
+    return dp;
+  };
+  d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
+  d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
+  d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
+  d.asdir = in(a->asdir, N, "asdir", true); d.asdif = in(a->asdif, N, "asdif", true);
+  d.aldir = in(a->aldir, N, "aldir", true); d.aldif = in(a->aldif, N, "aldif", true);
+  d.coszen = in(a->coszen, N, "coszen", true);
+  const bool clouds = d.icld >= 1;
+  if (clouds) {
+    d.cldfr = in(a->cldfr, nl, "cldfr", true);
+    const bool optics = (d.inflag == 0);
+    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics);
+    d.ssacld = in(a->ssacld, nl * kSwNBand, "ssacld", optics);
+    d.asmcld = in(a->asmcld, nl * kSwNBand, "asmcld", optics);
+    d.fsfcld = in(a->fsfcld, nl * kSwNBand, "fsfcld", optics);
+    d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag == 2); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag == 2);
+    d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
+  }
+  const double *ecaer = nullptr;
+  if (d.iaer == 10) {
+    d.tauaer = in(a->tauaer, nl * kSwNBand, "tauaer", true); d.ssaaer = in(a->ssaaer, nl * kSwNBand, "ssaaer", true);
+    d.asmaer = in(a->asmaer, nl * kSwNBand, "asmaer", true);
+  } else if (d.iaer == 6) {
+    ecaer = in(a->ecaer, nl * 6, "ecaer", true);
+  }
+  if (!ok) return ctx->status;
+
+  // ---- work buffers -------------------------------------------------------------------------
+  auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("sw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
+  d.fac00 = wd("fac00", nl); d.fac01 = wd("fac01", nl); d.fac10 = wd("fac10", nl); d.fac11 = wd("fac11", nl);
+  d.selffac = wd("selffac", nl); d.selffrac = wd("selffrac", nl); d.forfac = wd("forfac", nl); d.forfrac = wd("forfrac", nl);
+  d.colh2o = wd("colh2o", nl); d.colco2 = wd("colco2", nl); d.colo3 = wd("colo3", nl); d.colch4 = wd("colch4", nl);
+  d.colo2 = wd("colo2", nl); d.colmol = wd("colmol", nl); d.pdp = wd("pdp", nl); d.cossza = wd("cossza", N);
+  d.idx = (int32_t *)ctx->buf("sw.w.idx", nl * 4); d.laytrop = (int32_t *)ctx->buf("sw.w.laytrop", (size_t)N * 4);
+  d.laysolfr = (int32_t *)ctx->buf("sw.w.laysolfr", (size_t)N * 4 * kSwNBand); d.anycld = (int32_t *)ctx->buf("sw.w.anycld", (size_t)N * 4);
+  if (!d.idx || !d.laytrop || !d.laysolfr || !d.anycld) ok = false;
+  if (clouds) { d.ctau = wd("ctau", nl * kSwNBand); d.cssa = wd("cssa", nl * kSwNBand); d.casm = wd("casm", nl * kSwNBand); }
+  d.nw = (L + 63) / 64;
+  if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
+  const int ntile = (N + 63) / 64;
+  d.scratch = wd("scratch", (size_t)ntile * 12 * F_NTOT * L * 64);
+  d.part = wd("part", (size_t)kSwNGpt * 4 * nl1);
+  if (a->memspace == 1) {
+    d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
+  } else {
+    d.swuflx = wd("o.uflx", nl1); d.swdflx = wd("o.dflx", nl1); d.swhr = wd("o.hr", nl); d.swuflxc = wd("o.uflxc", nl1); d.swdflxc = wd("o.dflxc", nl1); d.swhrc = wd("o.hrc", nl);
+  }
+  if (!ok) return ctx->status;
+  if (!a->swuflx || !a->swdflx || !a->swhr || !a->swuflxc || !a->swdflxc || !a->swhrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
+  d.err = ctx->err_dev;
+  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+
+  // ---- launches ---------------------------------------------------------------------------
+  const dim3 gcol(ntile), gcl(ntile, L), blk(64);
+  hipLaunchKernelGGL(sw_prep_kernel, gcol, blk, 0, s, d, T);
+  if (d.iaer == 6) {
+    double *ta = wd("aer.tau", nl * kSwNBand), *om = wd("aer.ssa", nl * kSwNBand), *as = wd("aer.asm", nl * kSwNBand);
+    if (!ok) return ctx->status;
+    hipLaunchKernelGGL(sw_aer_kernel, gcl, blk, 0, s, d, T, ecaer, ta, om, as);
+    d.tauaer = ta; d.ssaaer = om; d.asmaer = as;
+  }
+  if (clouds) {
+    hipLaunchKernelGGL(sw_cloud_kernel, gcl, blk, 0, s, d, T);
+    if (d.mcica) {
+      if (a->cldfmcl) {
+        const double *cm = in(a->cldfmcl, nl * kSwNGpt, "cldfmcl", true);
+        if (!ok) return ctx->status;
+        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, kSwNGpt, cm, d.mask, d.nw);
+      } else if (a->irng == 0) {
+        hipLaunchKernelGGL(kiss_mask_kernel, gcol, blk, 0, s, N, L, kSwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err);
+      } else {
+        std::vector<double> cf(nl);
+        if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
+        else cf.assign(a->cldfr, a->cldfr + nl);
+        std::vector<uint64_t> hm;
+        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw);
+        RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
+        RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      }
+    }
+  }
+  launch_solve<16>(d, T, s); launch_solve<17>(d, T, s); launch_solve<18>(d, T, s); launch_solve<19>(d, T, s);
+  launch_solve<20>(d, T, s); launch_solve<21>(d, T, s); launch_solve<22>(d, T, s); launch_solve<23>(d, T, s);
+  launch_solve<24>(d, T, s); launch_solve<25>(d, T, s); launch_solve<26>(d, T, s); launch_solve<27>(d, T, s);
+  launch_solve<28>(d, T, s); launch_solve<29>(d, T, s);
+  hipLaunchKernelGGL(sw_finish_kernel, gcol, blk, 0, s, d, T);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+
+  // ---- status + outputs -------------------------------------------------------------------
+  int herr = 0;
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (a->memspace == 0) {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swuflx, d.swuflx, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swdflx, d.swdflx, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swuflxc, d.swuflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swdflxc, d.swdflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swhr, d.swhr, nl * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swhrc, d.swhrc, nl * 8, hipMemcpyDeviceToHost, s));
+  }
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (herr) return ctx->fail(herr, "shortwave: %s", status_message(herr));
+  ctx->status = 0;
+  return RRTMG_OK;
+}
+
+}  // namespace rrtmg

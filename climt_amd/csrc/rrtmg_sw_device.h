@@ -1,0 +1,840 @@
+// rrtmg_sw_device.h -- RRTMG shortwave hot path as per-thread device functions (gfx950).
+//
+// Decomposition (MI355X-first, not the reference's per-column serial loops):
+//   sw_prep_column   one thread per column : inatm_sw + setcoef_sw + laysolfr bookkeeping
+//   sw_cloud_layer   one thread per (column, layer) : cldprop_sw / cldprmc_sw band optics
+//   sw_kiss_column   one thread per column : kissvec sub-column cloud mask (bit-packed)
+//   sw_solve_thread  one thread per (column, g-point); a wavefront = 64 columns x ONE g-point, so
+//                    band/g-point control flow is wave-uniform, every per-column input is a
+//                    coalesced 512-B row of the [layer][column] arrays, and k-table gathers of a
+//                    wave fall in one contiguous [g][index] slice.  Two sweeps over the layers:
+//                    up (taumol + delta scaling + reftra + upward adding recurrence, level state
+//                    spilled to a [field][layer][lane] scratch slab) and down (downward adding
+//                    recurrence + flux assembly).
+//   sw_finish_column spectral integration in g-point order + heating rates.
+//
+// Reference followed (climt/_lib/rrtmg_sw/): rrtmg_sw_rad.nomcica.f90:587-816 (driver),
+// :846-1539 (inatm_sw), rrtmg_sw_setcoef.f90:49-305, rrtmg_sw_taumol.f90:50-1790,
+// rrtmg_sw_cldprop.f90:53-365, rrtmg_sw_cldprmc.f90:53-349, rrtmg_sw_spcvrt.f90:53-667,
+// rrtmg_sw_spcvmc.f90, rrtmg_sw_reftra.f90:48-324, rrtmg_sw_vrtqdr.f90:47-171,
+// mcica_subcol_gen_sw.f90:182-591.
+#pragma once
+#include "rrtmg_common.h"
+
+namespace rrtmg {
+
+constexpr int kSwNBand = 14;
+constexpr int kSwNGpt = 112;
+
+struct SwBandTab {
+  int ng, gs;       // g-points in band, first g-point (0-based) of band
+  int nfor, nsrc;   // rows of forref (3|4); source mixtures (1, 5 or 9)
+  long absa, absb, self, forr;
+  long sflux, irr, fac, sns;   // [js][ig]
+  long rayl, raylb;            // rayl: [ng] (or [9][ng] band 24); raylb band 24 upper
+  long ex1, ex2;               // extra absorber tables (lower / upper)
+};
+
+struct SwTab {
+  const double *t;
+  SwBandTab b[kSwNBand];
+  long preflog, tref, exp_tbl;
+  long extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3;
+  long abari, bbari, cbari, dbari, ebari, fbari, wavenum2;
+  long rsrtaua, rsrpiza, rsrasya;
+  double heatfac;
+};
+
+// everything a launch needs; all arrays device-resident, [layer][column] with column fastest
+struct SwDev {
+  int ncol, nlay;
+  int icld, iaer, inflag, iceflag, liqflag, mcica, isolvar;
+  double adjflux;           // Earth-Sun factor (isolvar >= 0) -- per band array below for isolvar < 0
+  double adjflux_b[kSwNBand];
+  double svar_f, svar_s, svar_i;
+  double svar_b[kSwNBand];  // isolvar == 3: per-band multiplier (same for f, s, i)
+  Constants k;
+  // inputs
+  const double *play, *plev, *tlay, *h2o, *o3, *co2, *ch4, *n2o, *o2;
+  const double *asdir, *asdif, *aldir, *aldif, *coszen;
+  const double *cldfr, *taucld, *ssacld, *asmcld, *fsfcld, *cicewp, *cliqwp, *reice, *reliq;
+  const double *tauaer, *ssaaer, *asmaer;   // effective per-band aerosol [14][lay][col] or null
+  // prep products
+  double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac;
+  double *colh2o, *colco2, *colo3, *colch4, *colo2, *colmol;
+  int32_t *idx;        // jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<24
+  int32_t *laytrop;    // [col]
+  int32_t *laysolfr;   // [14][col], 1-based layer, 0 = source never set
+  int32_t *anycld;     // [col] nomcica: 1 if any layer has cldfr > 0
+  double *cossza;      // [col]
+  double *pdp;         // [lay][col]
+  double *ctau, *cssa, *casm;   // delta-scaled cloud optics [14][lay][col]
+  uint64_t *mask;      // McICA cloud mask bits [112][nw][col]
+  int nw;
+  double *scratch;     // per band launch: [block][field][lay][64]
+  double *part;        // [112][4][nlay+1][col]  weighted (fu, fd, cu, cd)
+  int *err;
+  // outputs
+  double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
+};
+
+enum { SP_H2O = 0, SP_CO2 = 1, SP_O3 = 2, SP_CH4 = 3, SP_O2 = 4 };
+
+// ------------------------------------------------------------------------------------------
+// inatm_sw (rrtmg_sw_rad.nomcica.f90:1441-1465) + setcoef_sw (rrtmg_sw_setcoef.f90:137-303)
+// ------------------------------------------------------------------------------------------
+RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
+  const int L = d.nlay, N = d.ncol;
+  const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
+  const double amd = 28.9660, amw = 18.0160;
+  const double stpfac = 296.0 / 1013.0;
+  int laytrop = 0;
+  int anycld = 0;
+  for (int l = 0; l < L; ++l) {
+    const long i = (long)l * N + col;
+    const double pz0 = d.plev[i], pz1 = d.plev[i + N];
+    const double pavel = d.play[i], tavel = d.tlay[i];
+    const double wh2o = d.h2o[i];
+    const double amm = (1.0 - wh2o) * amd + wh2o * amw;
+    const double coldry = (pz0 - pz1) * 1.e3 * d.k.avogad / (1.e2 * d.k.grav * amm * (1.0 + wh2o));
+    d.pdp[i] = pz0 - pz1;
+    const double w1 = coldry * wh2o, w2 = coldry * d.co2[i], w3 = coldry * d.o3[i];
+    const double w4 = coldry * d.n2o[i], w6 = coldry * d.ch4[i], w7 = coldry * d.o2[i];
+    (void)w4;
+
+    const double plog = log(pavel);
+    int jp = (int)(36.0 - 5 * (plog + 0.04));
+    if (jp < 1) jp = 1; else if (jp > 58) jp = 58;
+    const double fp = 5.0 * (preflog[jp - 1] - plog);
+    int jt = (int)(3.0 + (tavel - tref[jp - 1]) / 15.0);
+    if (jt < 1) jt = 1; else if (jt > 4) jt = 4;
+    const double ft = ((tavel - tref[jp - 1]) / 15.0) - (double)(jt - 3);
+    int jt1 = (int)(3.0 + (tavel - tref[jp]) / 15.0);
+    if (jt1 < 1) jt1 = 1; else if (jt1 > 4) jt1 = 4;
+    const double ft1 = ((tavel - tref[jp]) / 15.0) - (double)(jt1 - 3);
+    const double water = w1 / coldry;
+    const double scalefac = pavel * stpfac / tavel;
+    int indself, indfor;
+    double forfac, forfrac, selffac, selffrac;
+    if (plog > 4.56) {
+      laytrop++;
+      forfac = scalefac / (1. + water);
+      double factor = (332.0 - tavel) / 36.0;
+      int ifac = (int)factor;
+      indfor = ifac < 1 ? 1 : (ifac > 2 ? 2 : ifac);
+      forfrac = factor - (double)indfor;
+      selffac = water * forfac;
+      factor = (tavel - 188.0) / 7.2;
+      ifac = (int)factor - 7;
+      indself = ifac < 1 ? 1 : (ifac > 9 ? 9 : ifac);
+      selffrac = factor - (double)(indself + 7);
+    } else {
+      forfac = scalefac / (1. + water);
+      double factor = (tavel - 188.0) / 36.0;
+      indfor = 3;
+      forfrac = factor - 1.0;
+      selffac = 0.0;
+      selffrac = 0.0;
+      indself = 0;
+    }
+    double colh2o = 1.e-20 * w1, colco2 = 1.e-20 * w2, colo3 = 1.e-20 * w3;
+    double colch4 = 1.e-20 * w6, colo2 = 1.e-20 * w7;
+    const double colmol = 1.e-20 * coldry + colh2o;
+    if (colco2 == 0.0) colco2 = 1.e-32 * coldry;
+    if (colch4 == 0.0) colch4 = 1.e-32 * coldry;
+    if (colo2 == 0.0) colo2 = 1.e-32 * coldry;
+    const double compfp = 1.0 - fp;
+    d.fac10[i] = compfp * ft;
+    d.fac00[i] = compfp * (1.0 - ft);
+    d.fac11[i] = fp * ft1;
+    d.fac01[i] = fp * (1.0 - ft1);
+    d.selffac[i] = selffac; d.selffrac[i] = selffrac; d.forfac[i] = forfac; d.forfrac[i] = forfrac;
+    d.colh2o[i] = colh2o; d.colco2[i] = colco2; d.colo3[i] = colo3; d.colch4[i] = colch4;
+    d.colo2[i] = colo2; d.colmol[i] = colmol;
+    d.idx[i] = jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24);
+    if (d.icld >= 1 && d.cldfr) {
+      const double cf = d.cldfr[i];
+      if (cf > 0.0) anycld = 1;
+      // rrtmg_sw_rad.nomcica.f90:616-620
+      if (!d.mcica && cf > 1.e-6 && cf < 1.0 - 1.e-6) report_error(d.err, 10);
+    }
+  }
+  d.laytrop[col] = laytrop;
+  d.anycld[col] = anycld;
+  double cz = d.coszen[col];
+  if (cz < 1.e-10) cz = 1.e-10;   // rrtmg_sw_rad.nomcica.f90:641-642
+  d.cossza[col] = cz;
+
+  // layer at which each band takes its solar source term (rrtmg_sw_taumol.f90, per-band
+  // laysolfr logic; table SURVEY.md A.2).  Emulates the sequential update-and-test of the
+  // reference loops, result = last layer for which (lay == laysolfr) held.
+  const int layreffr[kSwNBand] = {18, 30, 6, 3, 3, 8, 2, 6, 1, 2, 0, 32, 58, 49};
+  const bool upper[kSwNBand] = {true, true, false, false, false, false, false, false, false, false, false, true, true, true};
+  for (int b = 0; b < kSwNBand; ++b) {
+    int fin = 0;
+    if (upper[b]) {
+      int ls = L;
+      for (int lay = laytrop + 1; lay <= L; ++lay) {
+        const int jpm = (lay >= 2) ? (d.idx[(long)(lay - 2) * N + col] & 0xff) : 0;
+        const int jpc = d.idx[(long)(lay - 1) * N + col] & 0xff;
+        if (jpm < layreffr[b] && jpc >= layreffr[b]) ls = lay;
+        if (lay == ls) fin = lay;
+      }
+    } else {
+      int ls = laytrop;
+      for (int lay = 1; lay <= laytrop; ++lay) {
+        if (b != 10) {  // band 26 has no layreffr test
+          const int jpc = d.idx[(long)(lay - 1) * N + col] & 0xff;
+          const int jpn = (lay < L) ? (d.idx[(long)lay * N + col] & 0xff) : 0;
+          if (jpc < layreffr[b] && jpn >= layreffr[b]) ls = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+        }
+        if (lay == ls) fin = lay;
+      }
+    }
+    d.laysolfr[(long)b * N + col] = fin;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// cloud optics by band for one (column, layer): cldprop_sw (rrtmg_sw_cldprop.f90:113-360);
+// cldprmc_sw computes the same numbers per g-point with ib = ngb(ig) (rrtmg_sw_cldprmc.f90:103-345)
+// so one band value serves every cloudy sub-column of the band.
+// ------------------------------------------------------------------------------------------
+RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
+  const int L = d.nlay, N = d.ncol;
+  const long i = (long)lay * N + col;
+  const double cldmin = 1.e-20, eps = 1.e-06;
+  const double *t = T.t;
+  const double ciwp = d.cicewp ? d.cicewp[i] : 0.0, clwp = d.cliqwp ? d.cliqwp[i] : 0.0;
+  const double cwp = ciwp + clwp;
+  const double cf = d.cldfr[i];
+  double tauctot = 0.0;
+  if (d.taucld) {
+    for (int b = 0; b < kSwNBand; ++b) tauctot = tauctot + d.taucld[i * kSwNBand + b];
+  }
+  // McICA gate is per sub-column (cldfmc >= cldmin and (cwp >= cldmin or taucmc >= cldmin)) with the
+  // band's tauc; nomcica gate uses the band-summed tauctot.
+  for (int b = 0; b < kSwNBand; ++b) {
+    const long o = ((long)b * L + lay) * N + col;
+    double tau = 0.0, ssa = 1.0, asy = 0.0;
+    const double tcb = d.taucld ? d.taucld[i * kSwNBand + b] : 0.0;
+    const bool gate = d.mcica ? (cwp >= cldmin || tcb >= cldmin) : (cf >= cldmin && (cwp >= cldmin || tauctot >= cldmin));
+    if (d.mcica) tau = tcb, ssa = d.ssacld ? d.ssacld[i * kSwNBand + b] : 1.0, asy = d.asmcld ? d.asmcld[i * kSwNBand + b] : 0.0;
+    if (gate) {
+      if (d.inflag == 0) {
+        const double ffp = d.fsfcld[i * kSwNBand + b];
+        const double ssac = d.ssacld[i * kSwNBand + b];
+        const double ffp1 = 1.0 - ffp, ffpssa = 1.0 - ffp * ssac;
+        ssa = ffp1 * ssac / ffpssa;
+        tau = ffpssa * tcb;
+        asy = (d.asmcld[i * kSwNBand + b] - ffp) / ffp1;
+      } else if (d.inflag == 2) {
+        double extcoice = 0, ssacoice = 0, gice = 0, forwice = 0;
+        double extcoliq = 0, ssacoliq = 0, gliq = 0, forwliq = 0;
+        const double radice = d.reice[i];
+        if (ciwp == 0.0) {
+        } else if (d.iceflag == 1) {
+          if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+          const double wn2 = t[T.wavenum2 + b];
+          int icx = 5;
+          if (wn2 > 1.43e04) icx = 1; else if (wn2 > 7.7e03) icx = 2; else if (wn2 > 5.3e03) icx = 3; else if (wn2 > 4.0e03) icx = 4;
+          extcoice = t[T.abari + icx - 1] + t[T.bbari + icx - 1] / radice;
+          ssacoice = 1.0 - t[T.cbari + icx - 1] - t[T.dbari + icx - 1] * radice;
+          gice = t[T.ebari + icx - 1] + t[T.fbari + icx - 1] * radice;
+          if (gice >= 1.0) gice = 1.0 - eps;
+          forwice = gice * gice;
+        } else if (d.iceflag == 2) {
+          if (radice < 5.0 || radice > 131.0) report_error(d.err, 11);
+          const double factor = (radice - 2.0) / 3.0;
+          int index = (int)factor;
+          if (index == 43) index = 42;
+          if (index < 1) index = 1;
+          const double fint = factor - (double)index;
+          const long k = (long)(index - 1) + 43 * b;
+          extcoice = t[T.extice2 + k] + fint * (t[T.extice2 + k + 1] - t[T.extice2 + k]);
+          ssacoice = t[T.ssaice2 + k] + fint * (t[T.ssaice2 + k + 1] - t[T.ssaice2 + k]);
+          gice = t[T.asyice2 + k] + fint * (t[T.asyice2 + k + 1] - t[T.asyice2 + k]);
+          forwice = gice * gice;
+        } else if (d.iceflag == 3) {
+          if (radice < 5.0 || radice > 140.0) report_error(d.err, 11);
+          const double factor = (radice - 2.0) / 3.0;
+          int index = (int)factor;
+          if (index == 46) index = 45;
+          if (index < 1) index = 1;
+          const double fint = factor - (double)index;
+          const long k = (long)(index - 1) + 46 * b;
+          extcoice = t[T.extice3 + k] + fint * (t[T.extice3 + k + 1] - t[T.extice3 + k]);
+          ssacoice = t[T.ssaice3 + k] + fint * (t[T.ssaice3 + k + 1] - t[T.ssaice3 + k]);
+          gice = t[T.asyice3 + k] + fint * (t[T.asyice3 + k + 1] - t[T.asyice3 + k]);
+          const double fdelta = t[T.fdlice3 + k] + fint * (t[T.fdlice3 + k + 1] - t[T.fdlice3 + k]);
+          if (fdelta < 0.0 || fdelta > 1.0) report_error(d.err, 13);
+          forwice = fdelta + 0.5 / ssacoice;
+          if (forwice > gice) forwice = gice;
+        } else {
+          report_error(d.err, 20);
+        }
+        if (ciwp != 0.0 && (extcoice < 0.0 || ssacoice > 1.0 || ssacoice < 0.0 || gice > 1.0 || gice < 0.0))
+          report_error(d.err, 13);
+        if (clwp == 0.0) {
+        } else if (d.liqflag == 1) {
+          const double radliq = d.reliq[i];
+          if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+          int index = (int)(radliq - 1.5);
+          if (index == 0) index = 1;
+          if (index == 58) index = 57;
+          if (index < 1) index = 1;
+          if (index > 57) index = 57;
+          const double fint = radliq - 1.5 - (double)index;
+          const long k = (long)(index - 1) + 58 * b;
+          extcoliq = t[T.extliq1 + k] + fint * (t[T.extliq1 + k + 1] - t[T.extliq1 + k]);
+          ssacoliq = t[T.ssaliq1 + k] + fint * (t[T.ssaliq1 + k + 1] - t[T.ssaliq1 + k]);
+          if (fint < 0. && ssacoliq > 1.) ssacoliq = t[T.ssaliq1 + k];
+          gliq = t[T.asyliq1 + k] + fint * (t[T.asyliq1 + k + 1] - t[T.asyliq1 + k]);
+          forwliq = gliq * gliq;
+          if (extcoliq < 0.0 || ssacoliq > 1.0 || ssacoliq < 0.0 || gliq > 1.0 || gliq < 0.0) report_error(d.err, 13);
+        } else {
+          report_error(d.err, 20);
+        }
+        const double tauliqorig = clwp * extcoliq, tauiceorig = ciwp * extcoice;
+        const double ssaliq = ssacoliq * (1.0 - forwliq) / (1.0 - forwliq * ssacoliq);
+        const double tauliq = (1.0 - forwliq * ssacoliq) * tauliqorig;
+        const double ssaice = ssacoice * (1.0 - forwice) / (1.0 - forwice * ssacoice);
+        const double tauice = (1.0 - forwice * ssacoice) * tauiceorig;
+        const double scatliq = ssaliq * tauliq;
+        double scatice = ssaice * tauice;
+        tau = tauliq + tauice;
+        if (tau == 0.0) tau = cldmin;
+        if (scatice == 0.0) scatice = cldmin;
+        ssa = (scatliq + scatice) / tau;
+        if (d.iceflag == 3) {
+          asy = (1.0 / (scatliq + scatice)) *
+                (scatliq * (gliq - forwliq) / (1.0 - forwliq) + scatice * ((gice - forwice) / (1.0 - forwice)));
+        } else {
+          asy = (scatliq * (gliq - forwliq) / (1.0 - forwliq) + scatice * (gice - forwice) / (1.0 - forwice)) /
+                (scatliq + scatice);
+        }
+      }
+    }
+    d.ctau[o] = tau; d.cssa[o] = ssa; d.casm[o] = asy;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// kissvec sub-column generator for one column (mcica_subcol_gen_sw.f90:316-470, :557-591).
+// Draw order of the reference: sub-column outer, layer inner, after `changeSeed` warm-up draws.
+// Output: bit (lay & 63) of mask[(ig*nw + lay/64)*ncol + col] set when the sub-column is cloudy.
+// nsub = 112 (SW) or 140 (LW).
+// ------------------------------------------------------------------------------------------
+struct Kiss { int32_t s1, s2, s3, s4; };
+RRTMG_HD double kiss_next(Kiss &k) {
+  uint32_t a = (uint32_t)k.s1, b = (uint32_t)k.s2, c = (uint32_t)k.s3, e = (uint32_t)k.s4;
+  a = 69069u * a + 1327217885u;
+  b ^= b << 13; b ^= b >> 17; b ^= b << 5;
+  // ishft(seed,-16) is a LOGICAL shift; iand(seed,65535)
+  c = 18000u * (c & 65535u) + (c >> 16);
+  e = 30903u * (e & 65535u) + (e >> 16);
+  k.s1 = (int32_t)a; k.s2 = (int32_t)b; k.s3 = (int32_t)c; k.s4 = (int32_t)e;
+  const int32_t kiss = (int32_t)(a + b + (c << 16) + e);
+  return (double)kiss * 2.328306e-10 + 0.5;
+}
+
+RRTMG_HD void kiss_mask_column(int ncol, int nlay, int nsub, int icld, int changeSeed, const double *play,
+                               const double *cldfr, uint64_t *mask, int nw, int *err, int col) {
+  const int N = ncol, L = nlay;
+  const double cldmin = 1.0e-20;
+  for (int g = 0; g < nsub; ++g)
+    for (int w = 0; w < nw; ++w) mask[((long)g * nw + w) * N + col] = 0ull;
+  if (icld == 0) return;
+  if (L < 4) { report_error(err, 4); return; }
+  Kiss k;
+  {
+    const double p1 = play[col] * 1.e2, p2 = play[(long)N + col] * 1.e2;
+    const double p3 = play[2l * N + col] * 1.e2, p4 = play[3l * N + col] * 1.e2;
+    if (p1 < p2) { report_error(err, 14); return; }
+    k.s1 = (int32_t)((p1 - (double)(int)p1) * 1000000000.0);
+    k.s2 = (int32_t)((p2 - (double)(int)p2) * 1000000000.0);
+    k.s3 = (int32_t)((p3 - (double)(int)p3) * 1000000000.0);
+    k.s4 = (int32_t)((p4 - (double)(int)p4) * 1000000000.0);
+  }
+  for (int i = 0; i < changeSeed; ++i) (void)kiss_next(k);
+  for (int g = 0; g < nsub; ++g) {
+    double cdf_prev = 0.0, cmax = 0.0;
+    if (icld == 3) cmax = kiss_next(k);
+    for (int l = 0; l < L; ++l) {
+      double cf = cldfr[(long)l * N + col];
+      if (cf < cldmin) cf = 0.0;
+      double cdf;
+      if (icld == 3) {
+        cdf = cmax;
+      } else {
+        cdf = kiss_next(k);
+        if (icld == 2 && l > 0) {
+          double cfm = cldfr[(long)(l - 1) * N + col];
+          if (cfm < cldmin) cfm = 0.0;
+          if (cdf_prev > 1.0 - cfm) cdf = cdf_prev; else cdf = cdf * (1.0 - cfm);
+        }
+      }
+      cdf_prev = cdf;
+      if (cdf >= 1.0 - cf) mask[((long)g * nw + (l >> 6)) * N + col] |= (1ull << (l & 63));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// transmittance table / two-stream layer operators
+// ------------------------------------------------------------------------------------------
+RRTMG_HD double sw_exp_lookup(const double *exp_tbl, double x) {
+  const double tblind = x / (kBpade + x);
+  const int itind = (int)(kTblInt * tblind + 0.5);
+  return exp_tbl[itind];
+}
+
+// direct-beam transmittance of a layer (rrtmg_sw_spcvrt.f90:562-574)
+RRTMG_HD double sw_dbt(const double *exp_tbl, double tau, double prmu0) {
+  const double ze1 = tau / prmu0;
+  if (ze1 <= 0.06) return 1.0 - ze1 + 0.5 * ze1 * ze1;
+  return sw_exp_lookup(exp_tbl, ze1);
+}
+
+// reftra_sw for one layer, kmodts = 2 (rrtmg_sw_reftra.f90:148-316)
+RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double zto1, double zw, double &pref,
+                        double &prefd, double &ptra, double &ptrad) {
+  const double eps = 1.e-08, zwcrit = 0.9999995, od_lo = 0.06;
+  const double zg3 = 3.0 * zg;
+  const double zgamma1 = (8.0 - zw * (5.0 + zg3)) * 0.25;
+  const double zgamma2 = 3.0 * (zw * (1.0 - zg)) * 0.25;
+  const double zgamma3 = (2.0 - zg3 * prmuz) * 0.25;
+  const double zgamma4 = 1.0 - zgamma3;
+  const double zq = zg / (1.0 - zg);
+  const double zwo = zw / (1.0 - (1.0 - zw) * (zq * zq));
+  if (zwo >= zwcrit) {
+    const double za = zgamma1 * prmuz;
+    const double za1 = za - zgamma3;
+    const double zgt = zgamma1 * zto1;
+    double ze1 = zto1 / prmuz;
+    if (ze1 > 500.0) ze1 = 500.0;
+    double ze2;
+    if (ze1 <= od_lo) ze2 = 1.0 - ze1 + 0.5 * ze1 * ze1; else ze2 = sw_exp_lookup(exp_tbl, ze1);
+    pref = (zgt - za1 * (1.0 - ze2)) / (1.0 + zgt);
+    ptra = 1.0 - pref;
+    prefd = zgt / (1.0 + zgt);
+    ptrad = 1.0 - prefd;
+    if (ze2 == 1.0) { pref = 0.0; ptra = 1.0; prefd = 0.0; ptrad = 1.0; }
+  } else {
+    const double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
+    const double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
+    const double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+    const double zrp = zrk * prmuz;
+    const double zrp1 = 1.0 + zrp, zrm1 = 1.0 - zrp;
+    const double zrk2 = 2.0 * zrk;
+    const double zrpp = 1.0 - zrp * zrp;
+    const double zrkg = zrk + zgamma1;
+    const double zr1 = zrm1 * (za2 + zrk * zgamma3);
+    const double zr2 = zrp1 * (za2 - zrk * zgamma3);
+    const double zr3 = zrk2 * (zgamma3 - za2 * prmuz);
+    const double zr4 = zrpp * zrkg;
+    const double zr5 = zrpp * (zrk - zgamma1);
+    const double zt1 = zrp1 * (za1 + zrk * zgamma4);
+    const double zt2 = zrm1 * (za1 - zrk * zgamma4);
+    const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
+    const double zbeta = (zgamma1 - zrk) / zrkg;
+    double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
+    double ze2 = zto1 / prmuz; if (ze2 > 500.0) ze2 = 500.0;
+    double zem1, zem2;
+    if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
+    const double zep1 = 1.0 / zem1;
+    if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
+    const double zep2 = 1.0 / zem2;
+    const double zdenr = zr4 * zep1 + zr5 * zem1;
+    const double zdent = zr4 * zep1 + zr5 * zem1;   // zt4 = zr4, zt5 = zr5
+    if (zdenr >= -eps && zdenr <= eps) {
+      pref = eps;
+      ptra = zem2;
+    } else {
+      pref = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
+      ptra = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
+    }
+    const double zemm = zem1 * zem1;
+    const double zdend = 1.0 / ((1.0 - zbeta * zemm) * zrkg);
+    prefd = zgamma2 * (1.0 - zemm) * zdend;
+    ptrad = zrk2 * zem1 * zdend;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// taumol_sw for one (layer, g-point) of band BAND (rrtmg_sw_taumol.f90 taumol16..29).
+// ------------------------------------------------------------------------------------------
+struct SwLayerIn {
+  double fac00, fac01, fac10, fac11, selffac, selffrac, forfac, forfrac;
+  double colh2o, colco2, colo3, colch4, colo2, colmol;
+  int jp, jt, jt1, indself, indfor;
+};
+
+RRTMG_HD void sw_load_layer(const SwDev &d, long i, SwLayerIn &s) {
+  s.fac00 = d.fac00[i]; s.fac01 = d.fac01[i]; s.fac10 = d.fac10[i]; s.fac11 = d.fac11[i];
+  s.selffac = d.selffac[i]; s.selffrac = d.selffrac[i]; s.forfac = d.forfac[i]; s.forfrac = d.forfrac[i];
+  s.colh2o = d.colh2o[i]; s.colco2 = d.colco2[i]; s.colo3 = d.colo3[i]; s.colch4 = d.colch4[i];
+  s.colo2 = d.colo2[i]; s.colmol = d.colmol[i];
+  const int p = d.idx[i];
+  s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xff; s.indfor = (p >> 24) & 0xff;
+}
+
+struct SwSpec { int js; double fs; double speccomb; };
+
+RRTMG_HD SwSpec sw_specparm(double colx, double coly, double strrat, double mult) {
+  SwSpec r;
+  r.speccomb = colx + strrat * coly;
+  double specparm = colx / r.speccomb;
+  const double oneminus = 1.0 - 1.e-6;
+  if (specparm >= oneminus) specparm = oneminus;
+  const double specmult = mult * specparm;
+  r.js = 1 + (int)specmult;
+  r.fs = specmult - (double)(int)specmult;   // mod(specmult, 1)
+  return r;
+}
+
+// 8-point (binary species) major-gas sum, d1/d2 = offsets of the next-temperature rows
+RRTMG_HD double sw_m8(const double *k, int i0, int i1, int dT, const SwLayerIn &s, double fs) {
+  const double fac000 = (1.0 - fs) * s.fac00, fac010 = (1.0 - fs) * s.fac10;
+  const double fac100 = fs * s.fac00, fac110 = fs * s.fac10;
+  const double fac001 = (1.0 - fs) * s.fac01, fac011 = (1.0 - fs) * s.fac11;
+  const double fac101 = fs * s.fac01, fac111 = fs * s.fac11;
+  return fac000 * k[i0] + fac100 * k[i0 + 1] + fac010 * k[i0 + dT] + fac110 * k[i0 + dT + 1] +
+         fac001 * k[i1] + fac101 * k[i1 + 1] + fac011 * k[i1 + dT] + fac111 * k[i1 + dT + 1];
+}
+RRTMG_HD double sw_m4(const double *k, int i0, int i1, const SwLayerIn &s) {
+  return s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1];
+}
+RRTMG_HD double sw_selfterm(const double *selfref, const SwLayerIn &s) {  // selffac*(selfref + selffrac*(d))
+  const double a = selfref[s.indself - 1], b = selfref[s.indself];
+  return s.selffac * (a + s.selffrac * (b - a));
+}
+RRTMG_HD double sw_forinterp(const double *forref, const SwLayerIn &s) {  // forref + forfrac*(d)
+  const double a = forref[s.indfor - 1], b = forref[s.indfor];
+  return a + s.forfrac * (b - a);
+}
+
+template <int BAND> struct SwBandCfg;
+#define SW_CFG(B, NSPA, NSPB, LOX, LOY, STR, UPPERSRC, BINSRC)                     \
+  template <> struct SwBandCfg<B> {                                                \
+    static constexpr int nspa = NSPA, nspb = NSPB, lox = LOX, loy = LOY;           \
+    static constexpr double strrat = STR;                                          \
+    static constexpr bool upper_src = UPPERSRC, bin_src = BINSRC;                  \
+  };
+//      band nspa nspb key-lo-x  key-lo-y  strrat        src-in-upper  binary-src
+SW_CFG(16, 9, 1, SP_H2O, SP_CH4, 252.131, true, false)
+SW_CFG(17, 9, 5, SP_H2O, SP_CO2, 0.364641, true, true)
+SW_CFG(18, 9, 1, SP_H2O, SP_CH4, 38.9589, false, true)
+SW_CFG(19, 9, 1, SP_H2O, SP_CO2, 5.49281, false, true)
+SW_CFG(20, 1, 1, SP_H2O, -1, 0.0, false, false)
+SW_CFG(21, 9, 5, SP_H2O, SP_CO2, 0.0045321, false, true)
+SW_CFG(22, 9, 1, SP_H2O, SP_O2, 1.6 * 0.022708, false, true)
+SW_CFG(23, 1, 0, SP_H2O, -1, 0.0, false, false)
+SW_CFG(24, 9, 1, SP_H2O, SP_O2, 0.124692, false, true)
+SW_CFG(25, 1, 0, SP_H2O, -1, 0.0, false, false)
+SW_CFG(26, 0, 0, -1, -1, 0.0, false, false)
+SW_CFG(27, 1, 1, SP_O3, -1, 0.0, true, false)
+SW_CFG(28, 9, 5, SP_O3, SP_O2, 6.67029e-07, true, true)
+SW_CFG(29, 1, 1, SP_H2O, -1, 0.0, true, false)
+#undef SW_CFG
+
+RRTMG_HD double sw_col(const SwLayerIn &s, int sp) {
+  return sp == SP_H2O ? s.colh2o : sp == SP_CO2 ? s.colco2 : sp == SP_O3 ? s.colo3 : sp == SP_CH4 ? s.colch4 : s.colo2;
+}
+
+// Returns gas optical depth; sets Rayleigh optical depth. `lower` = layer index <= laytrop.
+template <int BAND>
+RRTMG_HD double sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig, double &taur) {
+  using C = SwBandCfg<BAND>;
+  const SwBandTab &B = T.b[BAND - 16];
+  const double *t = T.t;
+  const double *absa = t + B.absa + (long)ig * 65 * C::nspa;
+  const double *absb = t + B.absb + (long)ig * 235 * C::nspb;
+  const double *selfref = t + B.self + (long)ig * 10;
+  const double *forref = t + B.forr + (long)ig * B.nfor;
+  double taug = 0.0;
+  // Rayleigh: scalar per band (replicated per g at init), per g, or band 24's mixture-dependent form
+  double rayl = t[B.rayl + ig];
+  if (lower) {
+    if constexpr (C::nspa == 9) {
+      const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, 8.0);
+      const int i0 = ((s.jp - 1) * 5 + (s.jt - 1)) * 9 + sp.js - 1;
+      const int i1 = (s.jp * 5 + (s.jt1 - 1)) * 9 + sp.js - 1;
+      const double major = sp.speccomb * sw_m8(absa, i0, i1, 9, s, sp.fs);
+      if constexpr (BAND == 28) {
+        taug = major;
+      } else if constexpr (BAND == 24) {
+        taug = major + s.colo3 * t[B.ex1 + ig] +
+               s.colh2o * (sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
+        const double *ra = t + B.rayl;   // rayla(ig, js): [js][ig]
+        const double r0 = ra[ig + B.ng * (sp.js - 1)], r1 = ra[ig + B.ng * sp.js];
+        rayl = r0 + sp.fs * (r1 - r0);
+      } else {
+        taug = major + s.colh2o * (sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
+        if constexpr (BAND == 22) taug = taug + 4.35e-4 * s.colo2 / (350.0 * 2.0);
+      }
+    } else if constexpr (C::nspa == 1) {
+      const int i0 = ((s.jp - 1) * 5 + (s.jt - 1));
+      const int i1 = (s.jp * 5 + (s.jt1 - 1));
+      const double m4 = sw_m4(absa, i0, i1, s);
+      if constexpr (BAND == 20) {
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colch4 * t[B.ex1 + ig];
+      } else if constexpr (BAND == 29) {
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colco2 * t[B.ex1 + ig];
+      } else if constexpr (BAND == 23) {
+        taug = s.colh2o * (1.029 * m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
+      } else if constexpr (BAND == 25) {
+        taug = s.colh2o * m4 + s.colo3 * t[B.ex1 + ig];
+      } else {  // 27
+        taug = s.colo3 * m4;
+      }
+    } else {
+      taug = 0.0;  // band 26
+    }
+  } else {
+    if constexpr (C::nspb == 5) {
+      const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, 4.0);
+      const int i0 = ((s.jp - 13) * 5 + (s.jt - 1)) * 5 + sp.js - 1;
+      const int i1 = ((s.jp - 12) * 5 + (s.jt1 - 1)) * 5 + sp.js - 1;
+      const double major = sp.speccomb * sw_m8(absb, i0, i1, 5, s, sp.fs);
+      if constexpr (BAND == 28) taug = major;
+      else taug = major + s.colh2o * s.forfac * sw_forinterp(forref, s);
+    } else if constexpr (C::nspb == 1) {
+      const int i0 = ((s.jp - 13) * 5 + (s.jt - 1));
+      const int i1 = ((s.jp - 12) * 5 + (s.jt1 - 1));
+      if constexpr (BAND == 16 || BAND == 18) taug = s.colch4 * sw_m4(absb, i0, i1, s);
+      else if constexpr (BAND == 19) taug = s.colco2 * sw_m4(absb, i0, i1, s);
+      else if constexpr (BAND == 20)
+        taug = s.colh2o * (s.fac00 * absb[i0] + s.fac10 * absb[i0 + 1] + s.fac01 * absb[i1] + s.fac11 * absb[i1 + 1] +
+                           s.forfac * sw_forinterp(forref, s)) + s.colch4 * t[B.ex1 + ig];
+      else if constexpr (BAND == 22) taug = s.colo2 * 1.6 * sw_m4(absb, i0, i1, s) + 4.35e-4 * s.colo2 / (350.0 * 2.0);
+      else if constexpr (BAND == 24) { taug = s.colo2 * sw_m4(absb, i0, i1, s) + s.colo3 * t[B.ex2 + ig]; rayl = t[B.raylb + ig]; }
+      else if constexpr (BAND == 27) taug = s.colo3 * sw_m4(absb, i0, i1, s);
+      else taug = s.colco2 * sw_m4(absb, i0, i1, s) + s.colh2o * t[B.ex2 + ig];  // 29
+    } else {
+      if constexpr (BAND == 25) taug = s.colo3 * t[B.ex2 + ig];
+      else taug = 0.0;  // 23, 26
+    }
+  }
+  taur = s.colmol * rayl;
+  return taug;
+}
+
+// incoming solar flux of one g-point: zincflx = adjflux * (ssi | sfluxzen) * prmu0
+// (rrtmg_sw_spcvrt.f90:335-343; source selection rrtmg_sw_taumol.f90 "lay .eq. laysolfr" blocks)
+template <int BAND>
+RRTMG_HD double sw_incflux(const SwDev &d, const SwTab &T, int col, int ig, double prmu0) {
+  using C = SwBandCfg<BAND>;
+  const SwBandTab &B = T.b[BAND - 16];
+  const double *t = T.t;
+  const int b = BAND - 16;
+  const int ls = d.laysolfr[(long)b * d.ncol + col];
+  if (ls <= 0) return 0.0;
+  int js = 1;
+  double fs = 0.0;
+  if constexpr (C::bin_src) {
+    const long i = (long)(ls - 1) * d.ncol + col;
+    SwLayerIn s;
+    sw_load_layer(d, i, s);
+    const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, C::upper_src ? 4.0 : 8.0);
+    js = sp.js; fs = sp.fs;
+  }
+  auto src = [&](long base) {
+    if constexpr (C::bin_src) {
+      const double a = t[base + ig + B.ng * (js - 1)], c = t[base + ig + B.ng * js];
+      return a + fs * (c - a);
+    } else {
+      return t[base + ig];
+    }
+  };
+  double s;
+  if (d.isolvar < 0) {
+    s = src(B.sflux);
+    if constexpr (BAND == 27) s = (50.15 / 48.37) * t[B.sflux + ig];
+    return d.adjflux_b[b] * s * prmu0;
+  }
+  if (d.isolvar == 3)
+    s = d.svar_b[b] * src(B.fac) + d.svar_b[b] * src(B.sns) + d.svar_b[b] * src(B.irr);
+  else
+    s = d.svar_f * src(B.fac) + d.svar_s * src(B.sns) + d.svar_i * src(B.irr);
+  return d.adjflux * s * prmu0;
+}
+
+enum { F_REF = 0, F_REFD, F_TRA, F_TRAD, F_DBT, F_RUP, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
+
+// One (column, g-point): both sweeps.  scr -> this thread's element of a [field][layer][stride] slab.
+template <int BAND>
+RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, double *scr, long stride) {
+  const int L = d.nlay, N = d.ncol;
+  const int b = BAND - 16;
+  const int iw = T.b[b].gs + ig;
+  const double *exp_tbl = T.t + T.exp_tbl;
+  const double prmu0 = d.cossza[col];
+  const int laytrop = d.laytrop[col];
+  const double zinc = sw_incflux<BAND>(d, T, col, ig, prmu0);
+  // albedo by band: bands 1-9 and 14 near-IR, 10-13 UV/vis (rrtmg_sw_rad.nomcica.f90:648-659)
+  const bool vis = (b >= 9 && b <= 12);
+  const double albp = vis ? d.asdir[col] : d.aldir[col];
+  const double albd = vis ? d.asdif[col] : d.aldif[col];
+  // cloud presence for this thread
+  bool cloudy_col = false;
+  uint64_t mw[4] = {0, 0, 0, 0};
+  if (d.icld >= 1) {
+    if (d.mcica) {
+      for (int w = 0; w < d.nw && w < 4; ++w) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; cloudy_col |= (mw[w] != 0); }
+    } else {
+      cloudy_col = d.anycld[col] != 0;
+    }
+  }
+  auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
+
+  // ---- sweep 1: bottom -> top ---------------------------------------------------------------
+  double rupc = albp, rupdc = albd, rup = albp, rupd = albd;
+  for (int l = 0; l < L; ++l) {
+    const long i = (long)l * N + col;
+    SwLayerIn s;
+    sw_load_layer(d, i, s);
+    double taur;
+    const double taug = sw_taug<BAND>(T, s, (l + 1) <= laytrop, ig, taur);
+    double taua = 0.0, omga = 1.0, asya = 0.0;
+    if (d.tauaer) {
+      const long o = ((long)b * L + l) * N + col;
+      taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o];
+    }
+    // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
+    double ztauc = taur + taug + taua;
+    double zomcc = taur * 1.0 + taua * omga;
+    double zgcc = asya * omga * taua / zomcc;
+    zomcc = zomcc / ztauc;
+    {
+      const double zf = zgcc * zgcc, zwf = zomcc * zf;
+      ztauc = (1.0 - zwf) * ztauc;
+      zomcc = (zomcc - zwf) / (1.0 - zwf);
+      zgcc = (zgcc - zf) / (1.0 - zf);
+    }
+    double refc, refdc, trac, tradc;
+    sw_reftra(exp_tbl, zgcc, prmu0, ztauc, zomcc, refc, refdc, trac, tradc);
+    const double dbtc = sw_dbt(exp_tbl, ztauc, prmu0);
+    {
+      const double zr = 1.0 / (1.0 - rupdc * refdc);
+      const double nrup = refc + (tradc * ((trac - dbtc) * rupdc + dbtc * rupc)) * zr;
+      const double nrupd = refdc + tradc * tradc * rupdc * zr;
+      rupc = nrup; rupdc = nrupd;
+    }
+    S(F_REF, l) = refc; S(F_REFD, l) = refdc; S(F_TRA, l) = trac; S(F_TRAD, l) = tradc;
+    S(F_DBT, l) = dbtc; S(F_RUP, l) = rupc; S(F_RUPD, l) = rupdc;
+    if (cloudy_col) {
+      double ref = refc, refd = refdc, tra = trac, trad = tradc, dbt = dbtc;
+      bool lcld;
+      double zcloud;
+      if (d.mcica) { lcld = (mw[l >> 6] >> (l & 63)) & 1ull; zcloud = lcld ? 1.0 : 0.0; }
+      else { zcloud = d.cldfr[i]; lcld = zcloud > 1.e-12; }
+      const long o = ((long)b * L + l) * N + col;
+      const double ptauc = (lcld || !d.mcica) ? d.ctau[o] : 0.0;
+      if (lcld) {
+        const double pomgc = d.cssa[o], pasyc = d.casm[o];
+        // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
+        const double ztauo = ztauc + ptauc;
+        double zomco = ztauc * zomcc + ptauc * pomgc;
+        const double zgco = (ptauc * pomgc * pasyc + ztauc * zomcc * zgcc) / zomco;
+        zomco = zomco / ztauo;
+        double refo, refdo, trao, trado;
+        sw_reftra(exp_tbl, zgco, prmu0, ztauo, zomco, refo, refdo, trao, trado);
+        const double dbto = sw_dbt(exp_tbl, ztauo, prmu0);
+        if (d.mcica) {
+          ref = refo; refd = refdo; tra = trao; trad = trado; dbt = dbto;
+        } else {
+          const double zclear = 1.0 - zcloud;
+          ref = zclear * refc + zcloud * refo; refd = zclear * refdc + zcloud * refdo;
+          tra = zclear * trac + zcloud * trao; trad = zclear * tradc + zcloud * trado;
+          dbt = zclear * dbtc + zcloud * dbto;
+        }
+      } else if (!d.mcica && zcloud != 0.0) {
+        // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
+        const double zclear = 1.0 - zcloud;
+        const double dbto = sw_dbt(exp_tbl, ztauc + ptauc, prmu0);
+        ref = zclear * refc; refd = zclear * refdc; tra = zclear * trac + zcloud; trad = zclear * tradc + zcloud;
+        dbt = zclear * dbtc + zcloud * dbto;
+      }
+      const double zr = 1.0 / (1.0 - rupd * refd);
+      const double nrup = ref + (trad * ((tra - dbt) * rupd + dbt * rup)) * zr;
+      const double nrupd = refd + trad * trad * rupd * zr;
+      rup = nrup; rupd = nrupd;
+      S(F_NCLR + F_REF, l) = ref; S(F_NCLR + F_REFD, l) = refd; S(F_NCLR + F_TRA, l) = tra; S(F_NCLR + F_TRAD, l) = trad;
+      S(F_NCLR + F_DBT, l) = dbt; S(F_NCLR + F_RUP, l) = rup; S(F_NCLR + F_RUPD, l) = rupd;
+    }
+  }
+
+  // ---- sweep 2: top -> bottom; fluxes at every interface -------------------------------------
+  double *pfu = d.part + (((long)iw * 4 + 0) * (L + 1)) * N + col;
+  double *pfd = d.part + (((long)iw * 4 + 1) * (L + 1)) * N + col;
+  double *pcu = d.part + (((long)iw * 4 + 2) * (L + 1)) * N + col;
+  double *pcd = d.part + (((long)iw * 4 + 3) * (L + 1)) * N + col;
+  double tdnc = 1.0, rdndc = 0.0, tdbtc = 1.0, tdn = 1.0, rdnd = 0.0, tdbt = 1.0;
+  for (int lev = L; lev >= 0; --lev) {
+    const double rc = (lev > 0) ? S(F_RUP, lev - 1) : albp;
+    const double rdc = (lev > 0) ? S(F_RUPD, lev - 1) : albd;
+    double zr = 1.0 / (1.0 - rdndc * rdc);
+    const double cu = (tdbtc * rc + (tdnc - tdbtc) * rdc) * zr;
+    const double cd = tdbtc + (tdnc - tdbtc + tdbtc * rc * rdndc) * zr;
+    pcu[(long)lev * N] = zinc * cu;
+    pcd[(long)lev * N] = zinc * cd;
+    if (cloudy_col) {
+      const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1) : albp;
+      const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1) : albd;
+      zr = 1.0 / (1.0 - rdnd * rd);
+      const double fu = (tdbt * r + (tdn - tdbt) * rd) * zr;
+      const double fd = tdbt + (tdn - tdbt + tdbt * r * rdnd) * zr;
+      pfu[(long)lev * N] = zinc * fu;
+      pfd[(long)lev * N] = zinc * fd;
+    } else {
+      pfu[(long)lev * N] = zinc * cu;
+      pfd[(long)lev * N] = zinc * cd;
+    }
+    if (lev > 0) {
+      const int l = lev - 1;
+      {
+        const double ref = S(F_REF, l), refd = S(F_REFD, l), tra = S(F_TRA, l), trad = S(F_TRAD, l), dbt = S(F_DBT, l);
+        zr = 1.0 / (1.0 - refd * rdndc);
+        const double ntdn = tdbtc * tra + (trad * ((tdnc - tdbtc) + tdbtc * ref * rdndc)) * zr;
+        const double nrdnd = refd + trad * trad * rdndc * zr;
+        tdnc = ntdn; rdndc = nrdnd; tdbtc = dbt * tdbtc;
+      }
+      if (cloudy_col) {
+        const double ref = S(F_NCLR + F_REF, l), refd = S(F_NCLR + F_REFD, l), tra = S(F_NCLR + F_TRA, l),
+                     trad = S(F_NCLR + F_TRAD, l), dbt = S(F_NCLR + F_DBT, l);
+        zr = 1.0 / (1.0 - refd * rdnd);
+        const double ntdn = tdbt * tra + (trad * ((tdn - tdbt) + tdbt * ref * rdnd)) * zr;
+        const double nrdnd = refd + trad * trad * rdnd * zr;
+        tdn = ntdn; rdnd = nrdnd; tdbt = dbt * tdbt;
+      }
+    }
+  }
+}
+
+// spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
+// rrtmg_sw_rad.nomcica.f90:777-806)
+RRTMG_HD void sw_finish_column(const SwDev &d, const SwTab &T, int col) {
+  const int L = d.nlay, N = d.ncol;
+  double netp = 0.0, netcp = 0.0;
+  for (int lev = 0; lev <= L; ++lev) {
+    double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
+    for (int iw = 0; iw < kSwNGpt; ++iw) {
+      const double *p = d.part + ((long)iw * 4 * (L + 1) + lev) * N + col;
+      const long st = (long)(L + 1) * N;
+      fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
+    }
+    const long o = (long)lev * N + col;
+    d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
+    const double net = fd - fu, netc = cd - cu;
+    if (lev > 0) {
+      const long ol = (long)(lev - 1) * N + col;
+      const double zdpgcp = T.heatfac / d.pdp[ol];
+      d.swhrc[ol] = (netc - netcp) * zdpgcp;
+      d.swhr[ol] = (net - netp) * zdpgcp;
+    }
+    netp = net; netcp = netc;
+  }
+}
+
+}  // namespace rrtmg

@@ -1,0 +1,114 @@
+// rrtmg_sw_host.h -- host-side setup shared by the SW launch path: table descriptor construction and
+// the per-call scalar part of inatm_sw (Earth-Sun distance, solar-variability multipliers).
+#pragma once
+#include <cmath>
+#include <string>
+
+#include "rrtmg_sw_device.h"
+#include "rrtmg_tables.h"
+
+namespace rrtmg {
+
+// Fill the SwTab offsets from the reduced-table registry.  Scalar Rayleigh coefficients are
+// replicated per g-point so the kernel reads rayl[ig] for every band.
+inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
+  const std::vector<int32_t> *ngc = ts.ints("sw/wvn/ngc"), *ngs = ts.ints("sw/wvn/ngs");
+  if (!ngc || !ngs) { err = "sw/wvn/ngc missing"; return false; }
+  auto off = [&](const std::string &n, bool required) -> long {
+    long o = ts.off(n);
+    if (o < 0 && required) err = "reduced table '" + n + "' missing";
+    return o < 0 ? 0 : o;
+  };
+  for (int b = 0; b < kSwNBand; ++b) {
+    SwBandTab &B = T.b[b];
+    const std::string p = "sw/kg" + std::to_string(16 + b) + "/";
+    B.ng = (*ngc)[b];
+    B.gs = b == 0 ? 0 : (*ngs)[b - 1];
+    B.absa = off(p + "absa", false); B.absb = off(p + "absb", false);
+    B.self = off(p + "selfref", false); B.forr = off(p + "forref", false);
+    B.nfor = 4;
+    { auto it = ts.reg.find(p + "forref"); if (it != ts.reg.end()) B.nfor = (int)it->second.dims[0]; }
+    B.sflux = off(p + "sfluxref", true); B.irr = off(p + "irradnce", true);
+    B.fac = off(p + "facbrght", true); B.sns = off(p + "snsptdrk", true);
+    { auto it = ts.reg.find(p + "sfluxref"); B.nsrc = it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
+    B.raylb = 0; B.ex1 = 0; B.ex2 = 0;
+    const int band = 16 + b;
+    if (band == 24) {
+      B.rayl = off(p + "rayla", true); B.raylb = off(p + "raylb", true);
+      B.ex1 = off(p + "abso3a", true); B.ex2 = off(p + "abso3b", true);
+    } else {
+      auto it = ts.reg.find(p + "rayl");
+      if (it == ts.reg.end()) { err = "rayl missing for band " + std::to_string(band); return false; }
+      if (it->second.n == 1) {
+        std::vector<double> rep((size_t)B.ng, ts.flat[it->second.off]);
+        B.rayl = ts.add(p + "rayl_rep", rep.data(), B.ng, {(uint32_t)B.ng});
+      } else {
+        B.rayl = it->second.off;
+      }
+      if (band == 20) { B.ex1 = off(p + "absch4", true); }
+      if (band == 25) { B.ex1 = off(p + "abso3a", true); B.ex2 = off(p + "abso3b", true); }
+      if (band == 29) { B.ex1 = off(p + "absco2", true); B.ex2 = off(p + "absh2o", true); }
+    }
+    if (!err.empty()) return false;
+  }
+  T.preflog = off("sw/ref/preflog", true); T.tref = off("sw/ref/tref", true); T.exp_tbl = off("sw/tbl/exp_tbl", true);
+  T.extliq1 = off("sw/cld/extliq1", true); T.ssaliq1 = off("sw/cld/ssaliq1", true); T.asyliq1 = off("sw/cld/asyliq1", true);
+  T.extice2 = off("sw/cld/extice2", true); T.ssaice2 = off("sw/cld/ssaice2", true); T.asyice2 = off("sw/cld/asyice2", true);
+  T.extice3 = off("sw/cld/extice3", true); T.ssaice3 = off("sw/cld/ssaice3", true); T.asyice3 = off("sw/cld/asyice3", true);
+  T.fdlice3 = off("sw/cld/fdlice3", true);
+  T.abari = off("sw/cld/abari", true); T.bbari = off("sw/cld/bbari", true); T.cbari = off("sw/cld/cbari", true);
+  T.dbari = off("sw/cld/dbari", true); T.ebari = off("sw/cld/ebari", true); T.fbari = off("sw/cld/fbari", true);
+  T.wavenum2 = off("sw/wvn/wavenum2", true);
+  T.rsrtaua = off("sw/aer/rsrtaua", true); T.rsrpiza = off("sw/aer/rsrpiza", true); T.rsrasya = off("sw/aer/rsrasya", true);
+  T.heatfac = ts.heatfac;
+  return err.empty();
+}
+
+// earth_sun(idn) -- rrtmg_sw_rad.nomcica.f90:819-843
+inline double sw_earth_sun(int idn, double pi) {
+  const double gamma = 2.0 * pi * (idn - 1) / 365.0;
+  return 1.000110 + .034221 * cos(gamma) + .001289 * sin(gamma) + .000719 * cos(2.0 * gamma) + .000077 * sin(2.0 * gamma);
+}
+
+// Scalar part of inatm_sw: adjflux and the solar-variability multipliers
+// (rrtmg_sw_rad.nomcica.f90:1196-1428).  isolvar == 1 (NRLSSI2 solar-cycle tables) is not built.
+inline int sw_scalar_setup(SwDev &d, int isolvar, double adjes, int dyofyr, double scon, const double *bndsolvar,
+                           const double *indsolvar, std::string &err) {
+  const double rrsw_scon = (double)1.36822e+03f;   // parrrsw.f90:115 -- a default-real (single precision) literal
+  const double Iint = 1360.37, Fint = 0.996047, Sint = -0.511590;
+  const double Foffset = 0.14959542, Soffset = 0.00066696, svar_f_avg = 0.1568113, svar_s_avg = 909.21910;
+  double solvar[kSwNBand];
+  for (int b = 0; b < kSwNBand; ++b) { solvar[b] = 1.0; d.svar_b[b] = 1.0; }
+  d.svar_f = d.svar_s = d.svar_i = 1.0;
+  d.isolvar = isolvar;
+  if (isolvar < -1 || isolvar > 3 || isolvar == 1) {
+    err = "isolvar=" + std::to_string(isolvar) + " (solar-cycle interpolation) is not supported by this build";
+    return 20;
+  }
+  if (indsolvar && (indsolvar[0] != 1.0 || indsolvar[1] != 1.0)) {
+    // the reference rescales indsolvar IN PLACE once per column (inatm_sw is called inside the column
+    // loop, rrtmg_sw_rad.nomcica.f90:1196-1219), i.e. column-order dependent amplitudes; not reproduced.
+    err = "facular/sunspot amplitude scaling (indsolvar != 1) is not supported by this build";
+    return 20;
+  }
+  double adjflx = adjes;
+  if (dyofyr > 0) adjflx = sw_earth_sun(dyofyr, d.k.pi);
+  const double i1 = indsolvar ? indsolvar[0] : 1.0, i2 = indsolvar ? indsolvar[1] : 1.0;
+  if (scon == 0.0) {
+    if (isolvar == -1 && bndsolvar) for (int b = 0; b < kSwNBand; ++b) solvar[b] = bndsolvar[b];
+    if (isolvar == 2) { d.svar_f = (i1 - Foffset) / (svar_f_avg - Foffset); d.svar_s = (i2 - Soffset) / (svar_s_avg - Soffset); d.svar_i = 1.0; }
+    if (isolvar == 3) for (int b = 0; b < kSwNBand; ++b) { solvar[b] = bndsolvar ? bndsolvar[b] : 1.0; d.svar_b[b] = solvar[b]; }
+  } else if (scon > 0.0) {
+    if (isolvar == -1) for (int b = 0; b < kSwNBand; ++b) solvar[b] = bndsolvar ? bndsolvar[b] * scon / rrsw_scon : scon / rrsw_scon;
+    if (isolvar == 0) { const double r = scon / (Fint + Sint + Iint); d.svar_f = d.svar_s = d.svar_i = r; }
+    if (isolvar == 3) {
+      const double c = Fint + Sint + Iint;
+      for (int b = 0; b < kSwNBand; ++b) { solvar[b] = bndsolvar ? bndsolvar[b] * scon / c : scon / c; d.svar_b[b] = solvar[b]; }
+    }
+  }
+  d.adjflux = adjflx;
+  for (int b = 0; b < kSwNBand; ++b) d.adjflux_b[b] = (isolvar < 0) ? adjflx * solvar[b] : adjflx;
+  return 0;
+}
+
+}  // namespace rrtmg

@@ -1,0 +1,228 @@
+/*
+ * rrtmg_hip.h -- C-ABI of librrtmg_hip.so: MI355X (gfx950) RRTMG longwave + shortwave.
+ *
+ * Drop-in boundary for CliMT/climt's RRTMG path.  Two layers are exported:
+ *
+ *  (1) REFERENCE-COMPATIBLE ENTRY POINTS -- same symbol names, argument order, pass-by-pointer
+ *      scalars and array layouts as the Fortran bind(c) wrappers that climt's Cython shims bind
+ *      (climt/_components/rrtmg/sw/_rrtmg_sw.pyx:22-104, lw/_rrtmg_lw.pyx:19-80):
+ *        rrtmg_sw_set_constants      rrtmg_sw_c_binder.f90:19-46
+ *        rrtmg_sw_ini_wrapper        rrtmg_sw_c_binder.f90:48-57
+ *        mcica_subcol_sw_wrapper     rrtmg_sw_c_binder.f90:59-107
+ *        rrtmg_sw_mcica_wrapper      rrtmg_sw_c_binder.f90:109-200
+ *        rrtmg_sw_nomcica_wrapper    rrtmg_sw_c_binder.f90:202-294
+ *        rrtmg_set_constants         rrlw_con.f90:46-71   (the symbol _rrtmg_lw.pyx:20 binds)
+ *        rrtmg_lw_set_constants      rrtmg_lw_c_binder.f90:10-37
+ *        rrtmg_lw_ini_wrapper        rrtmg_lw_c_binder.f90:39-48
+ *        mcica_subcol_lw_wrapper     rrtmg_lw_c_binder.f90:50-92
+ *        rrtmg_lw_mcica_wrapper      rrtmg_lw_c_binder.f90:94-174
+ *        rrtmg_lw_nomcica_wrapper    rrtmg_lw_c_binder.f90:176-256
+ *      They operate on a process-global default context (the reference keeps the same state in
+ *      Fortran module variables) and take HOST pointers.  The reference aborts the process
+ *      (Fortran `stop`) on invalid input; these record an error instead, retrievable with
+ *      rrtmg_hip_default_status() / rrtmg_hip_default_error().
+ *
+ *  (2) CONTEXT API -- explicit context (one per GPU / per component instance), host or device
+ *      pointers, int status returns.  This is what climt_amd's Python host uses via ctypes.
+ *
+ * Array layout (both layers), identical to the reference boundary:
+ *   layer arrays      double[nlay][ncol]      (Fortran (ncol,nlay)); layer 0 = surface
+ *   interface arrays  double[nlay+1][ncol]
+ *   per-column        double[ncol]
+ *   cloud optics      double[nlay][ncol][nbnd]  (Fortran (nbnd,ncol,nlay))
+ *   aerosol           double[nbnd][nlay][ncol]  (Fortran (ncol,nlay,nbnd)); ecaer [6][nlay][ncol]
+ *   LW emissivity     double[16][ncol]
+ *   McICA sub-columns double[nlay][ncol][ngpt]  (Fortran (ngpt,ncol,nlay))
+ * No torch types, no ownership transfer: the caller owns every buffer.
+ */
+#ifndef RRTMG_HIP_H
+#define RRTMG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RRTMG_NBNDSW 14
+#define RRTMG_NGPTSW 112
+#define RRTMG_NBNDLW 16
+#define RRTMG_NGPTLW 140
+
+/* status codes: 0 ok; each former Fortran `stop` site maps to a distinct code */
+enum {
+  RRTMG_OK = 0,
+  RRTMG_ERR_HIP = 1,               /* HIP runtime failure (message has the hipError string) */
+  RRTMG_ERR_NOT_INITIALISED = 2,   /* *_init not called / tables missing */
+  RRTMG_ERR_TABLES = 3,            /* data blob unreadable or malformed */
+  RRTMG_ERR_ARG = 4,               /* bad argument (null pointer, nlay<=0, ...) */
+  RRTMG_ERR_PARTIAL_CLOUD = 10,    /* rrtmg_sw_rad.nomcica.f90:618 'PARTIAL CLOUD NOT ALLOWED' */
+  RRTMG_ERR_ICE_RADIUS = 11,       /* rrtmg_{sw,lw}_cldpr*.f90 'ICE RADIUS OUT OF BOUNDS' */
+  RRTMG_ERR_LIQ_RADIUS = 12,       /* 'LIQUID EFFECTIVE RADIUS OUT OF BOUNDS' */
+  RRTMG_ERR_CLOUD_OPTICS = 13,     /* negative extinction / ssa or g out of [0,1] */
+  RRTMG_ERR_KISS_PRESSURE = 14,    /* mcica_subcol_gen_*.f90 'KISSVEC SEED GENERATOR REQUIRES PMID...' */
+  RRTMG_ERR_ICLD = 15,             /* 'MCICA_SUBCOL: INVALID ICLD' */
+  RRTMG_ERR_UNSUPPORTED = 20       /* option not implemented in this build */
+};
+
+typedef struct rrtmg_ctx rrtmg_ctx;
+
+/* ---- context lifecycle -------------------------------------------------------------- */
+int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal);
+void rrtmg_hip_destroy(rrtmg_ctx *ctx);
+const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx);
+const char *rrtmg_hip_version(void);
+/* HIP stream (hipStream_t) all work of this context is enqueued on; for event timing. */
+void *rrtmg_hip_stream(rrtmg_ctx *ctx);
+int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
+
+/* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
+int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz,
+                            double clight, double avogad, double alosmt, double gascon,
+                            double sbcnst, double secdy);
+
+/* table construction + g-point reduction + upload; blob_path NULL -> "<dir of .so>/../data/rrtmg_{sw,lw}_data.bin"
+ * replaces rrtmg_sw_ini (rrtmg_sw_init.f90:47-173) / rrtmg_lw_ini (rrtmg_lw_init.f90:28-175) */
+int rrtmg_hip_sw_init(rrtmg_ctx *ctx, double cpdair, const char *blob_path);
+int rrtmg_hip_lw_init(rrtmg_ctx *ctx, double cpdair, const char *blob_path);
+/* 1 if the loaded LW k-distribution tables are synthetic (reference data file missing) */
+int rrtmg_hip_lw_tables_synthetic(const rrtmg_ctx *ctx);
+
+/* read back a reduced table built at init (for tests): name e.g. "sw/kg16/absa"; returns element count, or <0 */
+long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long capacity);
+
+/* ---- shortwave ------------------------------------------------------------------------ */
+typedef struct rrtmg_sw_args {
+  int32_t ncol, nlay;
+  int32_t memspace;     /* 0: all pointers are host memory; 1: all pointers are device memory */
+  int32_t mcica;        /* 0: rrtmg_sw_rad.nomcica.f90 path; 1: McICA path (rrtmg_sw_rad.f90) */
+  int32_t icld, iaer;   /* as the reference (icld 0..3; iaer 0/6/10) */
+  int32_t inflgsw, iceflgsw, liqflgsw;
+  int32_t dyofyr, isolvar;
+  int32_t irng;         /* McICA RNG: 0 kissvec, 1 Mersenne twister */
+  int32_t permuteseed;  /* McICA changeSeed */
+  int32_t reserved0;
+  double adjes, scon, solcycfrac;
+  const double *bndsolvar;   /* [14] (host) or NULL -> ones */
+  const double *indsolvar;   /* [2]  (host) or NULL -> ones */
+  /* state */
+  const double *play, *plev, *tlay, *tlev, *tsfc;
+  const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
+  const double *asdir, *asdif, *aldir, *aldif, *coszen;
+  /* clouds (NULL allowed when icld == 0; optics arrays NULL allowed when inflgsw != 0) */
+  const double *cldfr;
+  const double *taucld, *ssacld, *asmcld, *fsfcld;   /* [nlay][ncol][14] */
+  const double *cicewp, *cliqwp, *reice, *reliq;
+  /* aerosol (NULL allowed when iaer == 0) */
+  const double *tauaer, *ssaaer, *asmaer;            /* [14][nlay][ncol] */
+  const double *ecaer;                               /* [6][nlay][ncol]  */
+  /* McICA: optional externally generated sub-column cloud mask, [nlay][ncol][112] of 0.0/1.0
+   * (e.g. cldfmcl from mcica_subcol_sw_wrapper). NULL -> generated on the device (kissvec)
+   * or on the host and uploaded (Mersenne twister). */
+  const double *cldfmcl;
+  /* outputs */
+  double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
+} rrtmg_sw_args;
+
+int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a);
+
+/* ---- longwave ------------------------------------------------------------------------- */
+typedef struct rrtmg_lw_args {
+  int32_t ncol, nlay;
+  int32_t memspace;
+  int32_t mcica;
+  int32_t icld, idrv;
+  int32_t inflglw, iceflglw, liqflglw;
+  int32_t irng, permuteseed;
+  int32_t reserved0;
+  const double *play, *plev, *tlay, *tlev, *tsfc;
+  const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
+  const double *cfc11vmr, *cfc12vmr, *cfc22vmr, *ccl4vmr;
+  const double *emis;                                /* [16][ncol] */
+  const double *cldfr;
+  const double *taucld;                              /* [nlay][ncol][16] */
+  const double *cicewp, *cliqwp, *reice, *reliq;
+  const double *tauaer;                              /* [16][nlay][ncol]; NULL -> 0 */
+  const double *cldfmcl;                             /* optional [nlay][ncol][140] mask */
+  double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc;
+  double *duflx_dt, *duflxc_dt;                      /* idrv==1 only, [nlay+1][ncol] */
+} rrtmg_lw_args;
+
+int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a);
+
+/* sub-column generators on their own (mcica_subcol_gen_{sw,lw}.f90); host pointers.
+ * which: 0 = SW (112 sub-columns), 1 = LW (140).  cldfmcl out: [nlay][ncol][ngpt] of 0/1. */
+int rrtmg_hip_mcica_mask(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed,
+                         int irng, const double *play, const double *cldfrac, double *cldfmcl);
+
+/* ---- reference-compatible entry points (host pointers, default context) ---------------- */
+int rrtmg_hip_default_status(void);
+const char *rrtmg_hip_default_error(void);
+
+void rrtmg_sw_set_constants(double *pi, double *grav, double *planck, double *boltz, double *clight,
+                            double *avogad, double *alosmt, double *gascon, double *sbcnst, double *secdy);
+void rrtmg_sw_ini_wrapper(double *cpdair);
+void mcica_subcol_sw_wrapper(int32_t *iplon, int32_t *ncol, int32_t *nlay, int32_t *icld,
+                             int32_t *permuteseed, int32_t *irng, double *play, double *cldfrac,
+                             double *ciwp, double *clwp, double *rei, double *rel, double *tauc,
+                             double *ssac, double *asmc, double *fsfc, double *cldfmcl,
+                             double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl,
+                             double *taucmcl, double *ssacmcl, double *asmcmcl, double *fsfcmcl);
+void rrtmg_sw_mcica_wrapper(int32_t *ncol, int32_t *nlay, int32_t *icld, int32_t *iaer, double *play,
+                            double *plev, double *tlay, double *tlev, double *tsfc, double *h2ovmr,
+                            double *o3vmr, double *co2vmr, double *ch4vmr, double *n2ovmr, double *o2vmr,
+                            double *asdir, double *asdif, double *aldir, double *aldif, double *coszen,
+                            double *adjes, int32_t *dyofyr, double *scon, int32_t *isolvar,
+                            int32_t *inflgsw, int32_t *iceflgsw, int32_t *liqflgsw, double *cldfmcl,
+                            double *taucmcl, double *ssacmcl, double *asmcmcl, double *fsfcmcl,
+                            double *ciwpmcl, double *clwpmcl, double *reicmcl, double *relqmcl,
+                            double *tauaer, double *ssaaer, double *asmaer, double *ecaer,
+                            double *swuflx, double *swdflx, double *swhr, double *swuflxc,
+                            double *swdflxc, double *swhrc, double *bndsolvar, double *indsolvar,
+                            double *solcycfrac);
+void rrtmg_sw_nomcica_wrapper(int32_t *ncol, int32_t *nlay, int32_t *icld, int32_t *iaer, double *play,
+                              double *plev, double *tlay, double *tlev, double *tsfc, double *h2ovmr,
+                              double *o3vmr, double *co2vmr, double *ch4vmr, double *n2ovmr, double *o2vmr,
+                              double *asdir, double *asdif, double *aldir, double *aldif, double *coszen,
+                              double *adjes, int32_t *dyofyr, double *scon, int32_t *isolvar,
+                              int32_t *inflgsw, int32_t *iceflgsw, int32_t *liqflgsw, double *cldfr,
+                              double *taucld, double *ssacld, double *asmcld, double *fsfcld,
+                              double *cicewp, double *cliqwp, double *reice, double *reliq,
+                              double *tauaer, double *ssaaer, double *asmaer, double *ecaer,
+                              double *swuflx, double *swdflx, double *swhr, double *swuflxc,
+                              double *swdflxc, double *swhrc, double *bndsolvar, double *indsolvar,
+                              double *solcycfrac);
+
+void rrtmg_set_constants(double *pi, double *grav, double *planck, double *boltz, double *clight,
+                         double *avogad, double *alosmt, double *gascon, double *sbcnst, double *secdy);
+void rrtmg_lw_set_constants(double *pi, double *grav, double *planck, double *boltz, double *clight,
+                            double *avogad, double *alosmt, double *gascon, double *sbcnst, double *secdy);
+void rrtmg_lw_ini_wrapper(double *cpdair);
+void mcica_subcol_lw_wrapper(int32_t *iplon, int32_t *ncol, int32_t *nlay, int32_t *icld,
+                             int32_t *permuteseed, int32_t *irng, double *play, double *cldfrac,
+                             double *ciwp, double *clwp, double *rei, double *rel, double *tauc,
+                             double *cldfmcl, double *ciwpmcl, double *clwpmcl, double *reicmcl,
+                             double *relqmcl, double *taucmcl);
+void rrtmg_lw_mcica_wrapper(int32_t *ncol, int32_t *nlay, int32_t *icld, int32_t *idrv, double *play,
+                            double *plev, double *tlay, double *tlev, double *tsfc, double *h2ovmr,
+                            double *o3vmr, double *co2vmr, double *ch4vmr, double *n2ovmr, double *o2vmr,
+                            double *cfc11vmr, double *cfc12vmr, double *cfc22vmr, double *ccl4vmr,
+                            double *emis, int32_t *inflglw, int32_t *iceflglw, int32_t *liqflglw,
+                            double *cldfmcl, double *taucmcl, double *ciwpmcl, double *clwpmcl,
+                            double *reicmcl, double *relqmcl, double *tauaer, double *uflx, double *dflx,
+                            double *hr, double *uflxc, double *dflxc, double *hrc, double *duflx_dt,
+                            double *duflxc_dt);
+void rrtmg_lw_nomcica_wrapper(int32_t *ncol, int32_t *nlay, int32_t *icld, int32_t *idrv, double *play,
+                              double *plev, double *tlay, double *tlev, double *tsfc, double *h2ovmr,
+                              double *o3vmr, double *co2vmr, double *ch4vmr, double *n2ovmr, double *o2vmr,
+                              double *cfc11vmr, double *cfc12vmr, double *cfc22vmr, double *ccl4vmr,
+                              double *emis, int32_t *inflglw, int32_t *iceflglw, int32_t *liqflglw,
+                              double *cldfr, double *taucld, double *cicewp, double *cliqwp,
+                              double *reice, double *reliq, double *tauaer, double *uflx, double *dflx,
+                              double *hr, double *uflxc, double *dflxc, double *hrc, double *duflx_dt,
+                              double *duflxc_dt);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRTMG_HIP_H */

@@ -1,0 +1,226 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes driver for the *reference* RRTMG Fortran built by
+oracle/build_ref.sh into oracle/_ref/ (librrtmg_sw_ref.so, librrtmg_lw_ref.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+The product (climt_amd) never does.
+
+Entry points bound here are the reference's own bind(c) symbols:
+  SW: rrtmg_sw_set_constants / rrtmg_sw_ini_wrapper / mcica_subcol_sw_wrapper /
+      rrtmg_sw_{nomcica,mcica}_wrapper      (climt/_lib/rrtmg_sw/rrtmg_sw_c_binder.f90:19-294)
+  LW: rrtmg_set_constants (rrlw_con.f90:46-71) / rrtmg_lw_ini_wrapper /
+      mcica_subcol_lw_wrapper / rrtmg_lw_{nomcica,mcica}_wrapper
+                                            (climt/_lib/rrtmg_lw/rrtmg_lw_c_binder.f90:39-256)
+Array layout at this boundary: C-contiguous [layer, column] == Fortran (ncol, nlay).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REFDIR = os.path.join(HERE, "_ref")
+
+# values that reproduce the reference's golden caches ("Config / flags")
+CONSTANTS = dict(
+    pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852e-16,
+    clight=2.99792458e10, avogad=6.022140857e23, alosmt=2.6867774e19,
+    gascon=8.3144598e7, sbcnst=5.670367e-12, secdy=86400.0)
+CPDAIR = 1004.64
+
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+def _rd(x):
+    return C.byref(C.c_double(x))
+
+
+def _ri(x):
+    return C.byref(C.c_int32(x))
+
+
+def available(which="sw"):
+    return os.path.exists(os.path.join(REFDIR, "librrtmg_%s_ref.so" % which))
+
+
+def _cd(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+class _RefBase:
+    def __init__(self, which):
+        path = os.path.join(REFDIR, "librrtmg_%s_ref.so" % which)
+        self.lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+        self.which = which
+
+    def module_array(self, module, name, shape, dtype=np.float64):
+        """View of a Fortran module array (flang mangling _QM<module>E<name>), Fortran shape."""
+        sym = "_QM%sE%s" % (module.lower(), name.lower())
+        n = int(np.prod(shape))
+        ct = {np.float64: C.c_double, np.int32: C.c_int32}[dtype]
+        arr = (ct * n).in_dll(self.lib, sym)
+        return np.ctypeslib.as_array(arr).reshape(shape, order="F")
+
+    def module_scalar(self, module, name, dtype=np.float64):
+        return self.module_array(module, name, (1,), dtype)[0]
+
+
+class RefSW(_RefBase):
+    NB, NG = 14, 112
+
+    def __init__(self):
+        super().__init__("sw")
+        self.inited = False
+
+    def init(self, cpdair=CPDAIR, constants=CONSTANTS):
+        k = constants
+        self.lib.rrtmg_sw_set_constants(*[_rd(k[n]) for n in (
+            "pi", "grav", "planck", "boltz", "clight", "avogad", "alosmt", "gascon", "sbcnst", "secdy")])
+        self.lib.rrtmg_sw_ini_wrapper(_rd(cpdair))
+        self.inited = True
+
+    def fluxes(self, inp, mcica=False, subcol=None):
+        """inp: dict following the binder's argument names (see module docstring).
+        mcica=True: runs mcica_subcol_sw_wrapper first (permuteseed, irng from inp) unless
+        `subcol` (dict of pre-generated sub-column arrays) is given.  Returns dict of outputs."""
+        if not self.inited:
+            self.init()
+        nlay, ncol = inp["play"].shape
+        g = lambda k: _cd(inp[k])
+        z2 = lambda *s: np.zeros(s)
+        icld = C.c_int32(inp.get("icld", 1))
+        iaer = C.c_int32(inp.get("iaer", 0))
+        out = {k: z2(nlay + 1, ncol) for k in ("swuflx", "swdflx", "swuflxc", "swdflxc")}
+        out.update({k: z2(nlay, ncol) for k in ("swhr", "swhrc")})
+        dflt3 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol, 14), v)
+        taucld, ssacld = dflt3("taucld", 0.0), dflt3("ssacld", 1.0)
+        asmcld, fsfcld = dflt3("asmcld", 0.0), dflt3("fsfcld", 0.0)
+        aer = lambda k, v, n=14: _cd(inp[k]) if k in inp else np.full((n, nlay, ncol), v)
+        tauaer, ssaaer, asmaer, ecaer = aer("tauaer", 0.0), aer("ssaaer", 1.0), aer("asmaer", 0.0), aer("ecaer", 0.0, 6)
+        l2 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol), v)
+        cldfr, cicewp, cliqwp = l2("cldfr", 0.0), l2("cicewp", 0.0), l2("cliqwp", 0.0)
+        reice, reliq = l2("reice", 20.0), l2("reliq", 10.0)
+        bnd = _cd(inp.get("bndsolvar", np.ones(16)))
+        ind = _cd(inp.get("indsolvar", np.ones(2))).copy()
+        common_head = [_ri(ncol), _ri(nlay), C.byref(icld), C.byref(iaer),
+                       _d(g("play")), _d(g("plev")), _d(g("tlay")), _d(g("tlev")), _d(g("tsfc")),
+                       _d(g("h2o")), _d(g("o3")), _d(g("co2")), _d(g("ch4")), _d(g("n2o")), _d(g("o2")),
+                       _d(g("asdir")), _d(g("asdif")), _d(g("aldir")), _d(g("aldif")), _d(g("coszen")),
+                       _rd(inp.get("adjes", 1.0)), _ri(inp.get("dyofyr", 1)), _rd(inp.get("scon", 1367.0)),
+                       _ri(inp.get("isolvar", 0)), _ri(inp.get("inflg", 2)), _ri(inp.get("iceflg", 1)),
+                       _ri(inp.get("liqflg", 1))]
+        tail = [_d(tauaer), _d(ssaaer), _d(asmaer), _d(ecaer),
+                _d(out["swuflx"]), _d(out["swdflx"]), _d(out["swhr"]),
+                _d(out["swuflxc"]), _d(out["swdflxc"]), _d(out["swhrc"]),
+                _d(bnd), _d(ind), _rd(inp.get("solcycfrac", 0.0))]
+        if not mcica:
+            self.lib.rrtmg_sw_nomcica_wrapper(*(common_head + [
+                _d(cldfr), _d(taucld), _d(ssacld), _d(asmcld), _d(fsfcld),
+                _d(cicewp), _d(cliqwp), _d(reice), _d(reliq)] + tail))
+        else:
+            if subcol is None:
+                subcol = self.subcol(inp)
+            s = subcol
+            self.lib.rrtmg_sw_mcica_wrapper(*(common_head + [
+                _d(s["cldfmcl"]), _d(s["taucmcl"]), _d(s["ssacmcl"]), _d(s["asmcmcl"]), _d(s["fsfcmcl"]),
+                _d(s["ciwpmcl"]), _d(s["clwpmcl"]), _d(reice), _d(reliq)] + tail))
+            out["subcol"] = s
+        return out
+
+    def subcol(self, inp):
+        if not self.inited:
+            self.init()
+        nlay, ncol = inp["play"].shape
+        NG = self.NG
+        l2 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol), v)
+        dflt3 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol, 14), v)
+        s = {k: np.zeros((nlay, ncol, NG)) for k in
+             ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl", "ssacmcl", "asmcmcl", "fsfcmcl")}
+        s["reicmcl"] = np.zeros((nlay, ncol))
+        s["relqmcl"] = np.zeros((nlay, ncol))
+        irng = C.c_int32(inp.get("irng", 0))
+        self.lib.mcica_subcol_sw_wrapper(
+            _ri(1), _ri(ncol), _ri(nlay), _ri(inp.get("icld", 1)), _ri(inp.get("permuteseed", 1)),
+            C.byref(irng), _d(_cd(inp["play"])),
+            _d(l2("cldfr", 0.0)), _d(l2("cicewp", 0.0)), _d(l2("cliqwp", 0.0)),
+            _d(l2("reice", 20.0)), _d(l2("reliq", 10.0)),
+            _d(dflt3("taucld", 0.0)), _d(dflt3("ssacld", 1.0)), _d(dflt3("asmcld", 0.0)), _d(dflt3("fsfcld", 0.0)),
+            _d(s["cldfmcl"]), _d(s["ciwpmcl"]), _d(s["clwpmcl"]), _d(s["reicmcl"]), _d(s["relqmcl"]),
+            _d(s["taucmcl"]), _d(s["ssacmcl"]), _d(s["asmcmcl"]), _d(s["fsfcmcl"]))
+        return s
+
+
+class RefLW(_RefBase):
+    NB, NG = 16, 140
+
+    def __init__(self):
+        super().__init__("lw")
+        self.inited = False
+
+    def init(self, cpdair=CPDAIR, constants=CONSTANTS, fill_tables=None):
+        """fill_tables(self) is called before rrtmg_lw_ini so that the raw (16-g) rrlw_kgNN
+        module arrays can be filled with synthetic data (the loaders lw_kgbNN are empty)."""
+        k = constants
+        self.lib.rrtmg_set_constants(*[_rd(k[n]) for n in (
+            "pi", "grav", "planck", "boltz", "clight", "avogad", "alosmt", "gascon", "sbcnst", "secdy")])
+        if fill_tables is not None:
+            fill_tables(self)
+        self.lib.rrtmg_lw_ini_wrapper(_rd(cpdair))
+        self.inited = True
+
+    def subcol(self, inp):
+        nlay, ncol = inp["play"].shape
+        NG = self.NG
+        l2 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol), v)
+        tauc = _cd(inp["taucld"]) if "taucld" in inp else np.zeros((nlay, ncol, 16))
+        s = {k: np.zeros((nlay, ncol, NG)) for k in ("cldfmcl", "ciwpmcl", "clwpmcl", "taucmcl")}
+        s["reicmcl"] = np.zeros((nlay, ncol))
+        s["relqmcl"] = np.zeros((nlay, ncol))
+        irng = C.c_int32(inp.get("irng", 0))
+        self.lib.mcica_subcol_lw_wrapper(
+            _ri(1), _ri(ncol), _ri(nlay), _ri(inp.get("icld", 1)), _ri(inp.get("permuteseed", 1)),
+            C.byref(irng), _d(_cd(inp["play"])),
+            _d(l2("cldfr", 0.0)), _d(l2("cicewp", 0.0)), _d(l2("cliqwp", 0.0)),
+            _d(l2("reice", 20.0)), _d(l2("reliq", 10.0)), _d(tauc),
+            _d(s["cldfmcl"]), _d(s["ciwpmcl"]), _d(s["clwpmcl"]), _d(s["reicmcl"]), _d(s["relqmcl"]),
+            _d(s["taucmcl"]))
+        return s
+
+    def fluxes(self, inp, mcica=False, subcol=None):
+        assert self.inited
+        nlay, ncol = inp["play"].shape
+        g = lambda k: _cd(inp[k])
+        l2 = lambda k, v: _cd(inp[k]) if k in inp else np.full((nlay, ncol), v)
+        icld = C.c_int32(inp.get("icld", 1))
+        out = {k: np.zeros((nlay + 1, ncol)) for k in ("uflx", "dflx", "uflxc", "dflxc")}
+        out.update({k: np.zeros((nlay, ncol)) for k in ("hr", "hrc")})
+        idrv = inp.get("idrv", 0)
+        nd = nlay + 1 if idrv else 1
+        out["duflx_dt"] = np.zeros((nd, ncol))
+        out["duflxc_dt"] = np.zeros((nd, ncol))
+        emis = _cd(inp["emis"]) if "emis" in inp else np.ones((16, ncol))
+        tauaer = _cd(inp["tauaer"]) if "tauaer" in inp else np.zeros((16, nlay, ncol))
+        taucld = _cd(inp["taucld"]) if "taucld" in inp else np.zeros((nlay, ncol, 16))
+        head = [_ri(ncol), _ri(nlay), C.byref(icld), _ri(idrv),
+                _d(g("play")), _d(g("plev")), _d(g("tlay")), _d(g("tlev")), _d(g("tsfc")),
+                _d(g("h2o")), _d(g("o3")), _d(g("co2")), _d(g("ch4")), _d(g("n2o")), _d(g("o2")),
+                _d(l2("cfc11", 0.0)), _d(l2("cfc12", 0.0)), _d(l2("cfc22", 0.0)), _d(l2("ccl4", 0.0)),
+                _d(emis), _ri(inp.get("inflg", 2)), _ri(inp.get("iceflg", 1)), _ri(inp.get("liqflg", 1))]
+        tail = [_d(tauaer), _d(out["uflx"]), _d(out["dflx"]), _d(out["hr"]),
+                _d(out["uflxc"]), _d(out["dflxc"]), _d(out["hrc"]),
+                _d(out["duflx_dt"]), _d(out["duflxc_dt"])]
+        if not mcica:
+            self.lib.rrtmg_lw_nomcica_wrapper(*(head + [
+                _d(l2("cldfr", 0.0)), _d(taucld), _d(l2("cicewp", 0.0)), _d(l2("cliqwp", 0.0)),
+                _d(l2("reice", 20.0)), _d(l2("reliq", 10.0))] + tail))
+        else:
+            s = subcol if subcol is not None else self.subcol(inp)
+            self.lib.rrtmg_lw_mcica_wrapper(*(head + [
+                _d(s["cldfmcl"]), _d(s["taucmcl"]), _d(s["ciwpmcl"]), _d(s["clwpmcl"]),
+                _d(s["reicmcl"]), _d(s["relqmcl"])] + tail))
+            out["subcol"] = s
+        return out
