@@ -1,0 +1,6 @@
+"""climt_amd -- MI355X-native RRTMG longwave + shortwave radiation, drop-in for
+climt.RRTMGLongwave / climt.RRTMGShortwave (climt/_components/rrtmg/__init__.py:1-4)."""
+from ._lib import Context, RRTMGError  # noqa: F401
+from .rrtmg import RRTMGLongwave, RRTMGShortwave  # noqa: F401
+
+__all__ = ["RRTMGLongwave", "RRTMGShortwave", "Context", "RRTMGError"]

@@ -1,0 +1,210 @@
+"""ctypes binding of librrtmg_hip.so (include/rrtmg_hip.h) -- replaces climt's Cython shims
+_rrtmg_sw.pyx / _rrtmg_lw.pyx (climt/_components/rrtmg/{sw,lw}/).
+
+There is no CPU fallback: importing works anywhere (so property dictionaries can be inspected),
+but creating a Context without the built library or without a GPU raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "_lib", "librrtmg_hip.so")
+SW_DATA = os.path.join(HERE, "data", "rrtmg_sw_data.bin")
+LW_DATA = os.path.join(HERE, "data", "rrtmg_lw_data.bin")
+
+_vp, _i32, _f64 = C.c_void_p, C.c_int32, C.c_double
+
+
+class RRTMGError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("rrtmg_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class SwArgs(C.Structure):
+    _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld iaer inflgsw iceflgsw liqflgsw dyofyr isolvar "
+                                     "irng permuteseed reserved0").split()]
+                + [(n, _f64) for n in "adjes scon solcycfrac".split()]
+                + [(n, _vp) for n in ("bndsolvar indsolvar play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr "
+                                      "asdir asdif aldir aldif coszen cldfr taucld ssacld asmcld fsfcld cicewp cliqwp reice "
+                                      "reliq tauaer ssaaer asmaer ecaer cldfmcl swuflx swdflx swhr swuflxc swdflxc swhrc").split()])
+
+
+class LwArgs(C.Structure):
+    _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld idrv inflglw iceflglw liqflglw irng permuteseed "
+                                     "reserved0").split()]
+                + [(n, _vp) for n in ("play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr cfc11vmr cfc12vmr "
+                                      "cfc22vmr ccl4vmr emis cldfr taucld cicewp cliqwp reice reliq tauaer cldfmcl "
+                                      "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()])
+
+
+_lib = None
+
+
+def load_library():
+    """Load librrtmg_hip.so; raises ImportError (as climt does for its missing Fortran extension,
+    lw/component.py:253-257) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("librrtmg_hip.so has not been built (%s); run `python -c 'import __graft_entry__ as g; g.build()'`" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.rrtmg_hip_last_error.restype = C.c_char_p
+    lib.rrtmg_hip_last_error.argtypes = [_vp]
+    lib.rrtmg_hip_version.restype = C.c_char_p
+    lib.rrtmg_hip_stream.restype = _vp
+    lib.rrtmg_hip_stream.argtypes = [_vp]
+    lib.rrtmg_hip_create.argtypes = [C.POINTER(_vp), C.c_int]
+    lib.rrtmg_hip_destroy.argtypes = [_vp]
+    lib.rrtmg_hip_set_constants.argtypes = [_vp] + [_f64] * 10
+    lib.rrtmg_hip_sw_init.argtypes = [_vp, _f64, C.c_char_p]
+    lib.rrtmg_hip_lw_init.argtypes = [_vp, _f64, C.c_char_p]
+    lib.rrtmg_hip_sw_fluxes.argtypes = [_vp, C.POINTER(SwArgs)]
+    lib.rrtmg_hip_lw_fluxes.argtypes = [_vp, C.POINTER(LwArgs)]
+    lib.rrtmg_hip_get_table.restype = C.c_long
+    lib.rrtmg_hip_get_table.argtypes = [_vp, C.c_char_p, _vp, C.c_long]
+    lib.rrtmg_hip_lw_tables_synthetic.argtypes = [_vp]
+    lib.rrtmg_hip_synchronize.argtypes = [_vp]
+    lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
+    _lib = lib
+    return lib
+
+
+# the ten constants in the order of rrtmg_sw_set_constants (rrtmg_sw_c_binder.f90:19-46)
+CONSTANT_NAMES = ("pi", "grav", "planck", "boltz", "clight", "avogad", "alosmt", "gascon", "sbcnst", "secdy")
+
+# boundary-level names (left) -> SwArgs / LwArgs field (right)
+_SW_FIELDS = dict(play="play", plev="plev", tlay="tlay", tlev="tlev", tsfc="tsfc", h2o="h2ovmr", o3="o3vmr", co2="co2vmr",
+                  ch4="ch4vmr", n2o="n2ovmr", o2="o2vmr", asdir="asdir", asdif="asdif", aldir="aldir", aldif="aldif",
+                  coszen="coszen", cldfr="cldfr", taucld="taucld", ssacld="ssacld", asmcld="asmcld", fsfcld="fsfcld",
+                  cicewp="cicewp", cliqwp="cliqwp", reice="reice", reliq="reliq", tauaer="tauaer", ssaaer="ssaaer",
+                  asmaer="asmaer", ecaer="ecaer", cldfmcl="cldfmcl", bndsolvar="bndsolvar", indsolvar="indsolvar")
+_LW_FIELDS = dict(play="play", plev="plev", tlay="tlay", tlev="tlev", tsfc="tsfc", h2o="h2ovmr", o3="o3vmr", co2="co2vmr",
+                  ch4="ch4vmr", n2o="n2ovmr", o2="o2vmr", cfc11="cfc11vmr", cfc12="cfc12vmr", cfc22="cfc22vmr", ccl4="ccl4vmr",
+                  emis="emis", cldfr="cldfr", taucld="taucld", cicewp="cicewp", cliqwp="cliqwp", reice="reice", reliq="reliq",
+                  tauaer="tauaer", cldfmcl="cldfmcl")
+_SW_FLAGS = dict(icld="icld", iaer="iaer", inflg="inflgsw", iceflg="iceflgsw", liqflg="liqflgsw", dyofyr="dyofyr",
+                 isolvar="isolvar", irng="irng", permuteseed="permuteseed")
+_LW_FLAGS = dict(icld="icld", idrv="idrv", inflg="inflglw", iceflg="iceflglw", liqflg="liqflglw", irng="irng",
+                 permuteseed="permuteseed")
+SW_OUT = (("swuflx", 1), ("swdflx", 1), ("swhr", 0), ("swuflxc", 1), ("swdflxc", 1), ("swhrc", 0))
+LW_OUT = (("uflx", 1), ("dflx", 1), ("hr", 0), ("uflxc", 1), ("dflxc", 1), ("hrc", 0))
+
+
+class Context:
+    """One librrtmg_hip context: constants, device tables, work buffers, a HIP stream."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        h = _vp()
+        rc = self.lib.rrtmg_hip_create(C.byref(h), int(device))
+        self.h = h
+        self.device = device
+        if rc:
+            msg = self.lib.rrtmg_hip_last_error(self.h).decode() if self.h else "context creation failed"
+            raise RRTMGError(rc, msg)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rrtmg_hip_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc:
+            raise RRTMGError(rc, self.lib.rrtmg_hip_last_error(self.h).decode())
+
+    def set_constants(self, **k):
+        self._ck(self.lib.rrtmg_hip_set_constants(self.h, *[float(k[n]) for n in CONSTANT_NAMES]))
+
+    def sw_init(self, cpdair, blob=None):
+        self._ck(self.lib.rrtmg_hip_sw_init(self.h, float(cpdair), (blob or SW_DATA).encode()))
+
+    def lw_init(self, cpdair, blob=None):
+        self._ck(self.lib.rrtmg_hip_lw_init(self.h, float(cpdair), (blob or LW_DATA).encode()))
+
+    def lw_tables_synthetic(self):
+        return bool(self.lib.rrtmg_hip_lw_tables_synthetic(self.h))
+
+    @property
+    def stream(self):
+        return self.lib.rrtmg_hip_stream(self.h)
+
+    def synchronize(self):
+        self._ck(self.lib.rrtmg_hip_synchronize(self.h))
+
+    def get_table(self, name):
+        n = self.lib.rrtmg_hip_get_table(self.h, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n)
+        self.lib.rrtmg_hip_get_table(self.h, name.encode(), out.ctypes.data, n)
+        return out
+
+    # -- host-pointer calls: `inp` maps boundary names to numpy arrays (see _SW_FIELDS) -------
+    def _fill(self, a, inp, fields, flags, keep):
+        for k, f in flags.items():
+            if k in inp:
+                setattr(a, f, int(inp[k]))
+        for k, f in fields.items():
+            v = inp.get(k)
+            if v is None:
+                continue
+            if isinstance(v, (int, np.integer)):      # raw device pointer
+                setattr(a, f, int(v))
+            else:
+                arr = np.ascontiguousarray(v, dtype=np.float64)
+                keep.append(arr)
+                setattr(a, f, arr.ctypes.data)
+
+    def sw_fluxes(self, inp, mcica=False, out=None, memspace=0):
+        nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
+        a = SwArgs()
+        keep = []
+        a.ncol, a.nlay, a.memspace, a.mcica = int(ncol), int(nlay), int(memspace), int(bool(mcica))
+        a.icld, a.inflgsw, a.iceflgsw, a.liqflgsw, a.dyofyr = 1, 2, 1, 1, 1
+        a.adjes, a.scon, a.solcycfrac = float(inp.get("adjes", 1.0)), float(inp.get("scon", 1367.0)), float(inp.get("solcycfrac", 0.0))
+        self._fill(a, inp, _SW_FIELDS, _SW_FLAGS, keep)
+        if out is None:
+            out = {k: np.zeros((nlay + lev, ncol)) for k, lev in SW_OUT}
+        for k, _ in SW_OUT:
+            v = out[k]
+            setattr(a, k, int(v) if isinstance(v, (int, np.integer)) else v.ctypes.data)
+        self._ck(self.lib.rrtmg_hip_sw_fluxes(self.h, C.byref(a)))
+        return out
+
+    def lw_fluxes(self, inp, mcica=False, out=None, memspace=0):
+        nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
+        a = LwArgs()
+        keep = []
+        a.ncol, a.nlay, a.memspace, a.mcica = int(ncol), int(nlay), int(memspace), int(bool(mcica))
+        a.icld, a.inflglw, a.iceflglw, a.liqflglw = 1, 2, 1, 1
+        self._fill(a, inp, _LW_FIELDS, _LW_FLAGS, keep)
+        if out is None:
+            out = {k: np.zeros((nlay + lev, ncol)) for k, lev in LW_OUT}
+            if a.idrv:
+                out["duflx_dt"] = np.zeros((nlay + 1, ncol))
+                out["duflxc_dt"] = np.zeros((nlay + 1, ncol))
+        for k in out:
+            v = out[k]
+            setattr(a, k, int(v) if isinstance(v, (int, np.integer)) else v.ctypes.data)
+        self._ck(self.lib.rrtmg_hip_lw_fluxes(self.h, C.byref(a)))
+        return out
+
+    def mcica_mask(self, which, play, cldfrac, icld, permuteseed, irng):
+        nlay, ncol = play.shape
+        nsub = 112 if which == "sw" else 140
+        out = np.zeros((nlay, ncol, nsub))
+        p = np.ascontiguousarray(play, dtype=np.float64)
+        c = np.ascontiguousarray(cldfrac, dtype=np.float64)
+        self._ck(self.lib.rrtmg_hip_mcica_mask(self.h, 0 if which == "sw" else 1, ncol, nlay, int(icld), int(permuteseed),
+                                               int(irng), p.ctypes.data, c.ctypes.data, out.ctypes.data))
+        return out

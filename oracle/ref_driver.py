@@ -20,6 +20,15 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 REFDIR = os.path.join(HERE, "_ref")
 
+# The reference's sub-column generators keep (ngpt, ncol, nlay) automatic arrays on the stack
+# (mcica_subcol_gen_sw.f90:317); lift the soft stack limit so a few hundred columns fit.
+try:
+    import resource
+    _soft, _hard = resource.getrlimit(resource.RLIMIT_STACK)
+    resource.setrlimit(resource.RLIMIT_STACK, (_hard, _hard))
+except Exception:  # pragma: no cover
+    pass
+
 # values that reproduce the reference's golden caches ("Config / flags")
 CONSTANTS = dict(
     pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852e-16,
