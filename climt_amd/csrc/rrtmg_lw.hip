@@ -1,7 +1,219 @@
-// rrtmg_lw.hip -- longwave kernels and launch sequence (placeholder until the LW path lands)
+// rrtmg_lw.hip -- longwave kernels and launch sequence (gfx950).
+//
+// Launch sequence of one rrtmg_hip_lw_fluxes call (all on ctx->stream):
+//   lw_prep_kernel       <<<ncol/64>>>          inatm + setcoef per column
+//   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
+//   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
+//   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
+//   lw_solve_kernel<B>   16 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
+//   lw_finish_kernel     <<<ncol/64>>>
 #include "rrtmg_ctx.h"
+#include "rrtmg_lw_device.h"
+#include "rrtmg_lw_host.h"
+#include "rrtmg_mcica_kernels.h"
+
 namespace rrtmg {
-void free_lw_desc(rrtmg_ctx *ctx) { (void)ctx; }
-int lw_init_impl(rrtmg_ctx *ctx, double, const char *) { return ctx->fail(RRTMG_ERR_UNSUPPORTED, "longwave not built yet"); }
-int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *) { return ctx->fail(RRTMG_ERR_UNSUPPORTED, "longwave not built yet"); }
+
+__global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_prep_column(d, T, col);
+}
+__global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_cloud_column(d, T, col);
+}
+__global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_cloudmc_layer(d, T, col, blockIdx.y);
+}
+__global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_anymask_column(d, col);
+}
+template <int BAND>
+__global__ void __launch_bounds__(64) lw_solve_kernel(LwDev d, LwTab T) {
+  const int ng = T.b[BAND - 1].ng;
+  const int tile = blockIdx.x / ng, ig = blockIdx.x - tile * ng;
+  const int col = tile * 64 + threadIdx.x;
+  if (col >= d.ncol) return;
+  double *scr = d.scratch + (long)blockIdx.x * LF_N * d.nlay * 64 + threadIdx.x;
+  lw_solve_thread<BAND>(d, T, col, ig, scr, 64);
+}
+__global__ void __launch_bounds__(64) lw_finish_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_finish_column(d, T, col);
+}
+
+template <int BAND>
+static void launch_lw_solve(const LwDev &d, const LwTab &T, hipStream_t s) {
+  const int ntile = (d.ncol + 63) / 64;
+  hipLaunchKernelGGL(lw_solve_kernel<BAND>, dim3(ntile * T.b[BAND - 1].ng), dim3(64), 0, s, d, T);
+}
+
+void free_lw_desc(rrtmg_ctx *ctx) {
+  delete (LwTab *)ctx->lw_desc;
+  ctx->lw_desc = nullptr;
+}
+
+int lw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob_path) {
+  if (!ctx->have_constants) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "set_constants must be called before lw_init");
+  std::string path = blob_path ? std::string(blob_path) : default_blob_path("lw");
+  Blob blob;
+  std::string err;
+  if (!blob.load(path, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  ctx->lw_ts = TableSet();
+  if (!build_tables(blob, "lw", cpdair, ctx->k.grav, ctx->k.secdy, ctx->lw_ts, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  LwTab *T = ctx->lw_desc ? (LwTab *)ctx->lw_desc : new LwTab();
+  ctx->lw_desc = T;
+  if (!build_lw_tab(ctx->lw_ts, *T, err)) return ctx->fail(RRTMG_ERR_TABLES, "%s", err.c_str());
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
+  ctx->lw_tab_dev = nullptr;
+  RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->lw_tab_dev, ctx->lw_ts.flat.size() * sizeof(double)));
+  RRTMG_HIP_CHECK(ctx, hipMemcpy(ctx->lw_tab_dev, ctx->lw_ts.flat.data(), ctx->lw_ts.flat.size() * sizeof(double), hipMemcpyHostToDevice));
+  T->t = ctx->lw_tab_dev;
+  ctx->lw_ready = true;
+  return RRTMG_OK;
+}
+
+int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
+  if (!ctx->lw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_lw_init has not been called");
+  if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
+  if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const int N = a->ncol, L = a->nlay;
+  const size_t nl = (size_t)N * L, nl1 = (size_t)N * (L + 1);
+  const LwTab &T = *(LwTab *)ctx->lw_desc;
+  LwDev d{};
+  d.ncol = N; d.nlay = L;
+  d.icld = a->icld;
+  if (d.icld < 0 || d.icld > 3) d.icld = 2;   // rrtmg_lw_rad.nomcica.f90:436
+  d.idrv = a->idrv ? 1 : 0;
+  d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
+  d.k = ctx->k;
+  d.fluxfac = (2.0 * asin(1.0)) * 2.e4;       // rrtmg_lw_rad.nomcica.f90:420-421
+  if (!d.mcica && d.icld >= 2)
+    return ctx->fail(RRTMG_ERR_UNSUPPORTED, "non-McICA maximum/maximum-random overlap (rtrnmr) is not built yet; use mcica or icld<=1");
+  if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
+
+  bool ok = true;
+  auto in = [&](const double *p, size_t n, const char *name, bool required) -> const double * {
+    if (!p) {
+      if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
+      return nullptr;
+    }
+    if (a->memspace == 1) return p;
+    double *dp = (double *)ctx->buf(std::string("lw.in.") + name, n * sizeof(double));
+    if (!dp) { ok = false; return nullptr; }
+    if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
+    return dp;
+  };
+  d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
+  d.tlev = in(a->tlev, nl1, "tlev", true); d.tsfc = in(a->tsfc, N, "tsfc", true);
+  d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
+  d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
+  d.cfc11 = in(a->cfc11vmr, nl, "cfc11", false); d.cfc12 = in(a->cfc12vmr, nl, "cfc12", false);
+  d.cfc22 = in(a->cfc22vmr, nl, "cfc22", false); d.ccl4 = in(a->ccl4vmr, nl, "ccl4", false);
+  d.emis = in(a->emis, (size_t)N * 16, "emis", true);
+  d.tauaer = in(a->tauaer, nl * 16, "tauaer", false);
+  const bool clouds = d.icld >= 1;
+  if (clouds) {
+    d.cldfr = in(a->cldfr, nl, "cldfr", true);
+    d.taucld = in(a->taucld, nl * 16, "taucld", d.inflag == 0);
+    d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag >= 1); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag >= 1);
+    d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
+  }
+  if (!ok) return ctx->status;
+
+  auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("lw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
+  d.fac00 = wd("fac00", nl); d.fac01 = wd("fac01", nl); d.fac10 = wd("fac10", nl); d.fac11 = wd("fac11", nl);
+  d.selffac = wd("selffac", nl); d.selffrac = wd("selffrac", nl); d.forfac = wd("forfac", nl); d.forfrac = wd("forfrac", nl);
+  d.minorfrac = wd("minorfrac", nl); d.scaleminor = wd("scaleminor", nl); d.scaleminorn2 = wd("scaleminorn2", nl);
+  d.colh2o = wd("colh2o", nl); d.colco2 = wd("colco2", nl); d.colo3 = wd("colo3", nl); d.coln2o = wd("coln2o", nl);
+  d.colco = wd("colco", nl); d.colch4 = wd("colch4", nl); d.colo2 = wd("colo2", nl); d.colbrd = wd("colbrd", nl); d.coldry = wd("coldry", nl);
+  d.wx1 = wd("wx1", nl); d.wx2 = wd("wx2", nl); d.wx3 = wd("wx3", nl); d.wx4 = wd("wx4", nl);
+  d.secdiff = wd("secdiff", (size_t)N * 16);
+  d.idx = (int32_t *)ctx->buf("lw.w.idx", nl * 4); d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
+  d.ncbands = (int32_t *)ctx->buf("lw.w.ncbands", (size_t)N * 4);
+  if (!d.idx || !d.laytrop || !d.ncbands) ok = false;
+  if (clouds) d.ctau = wd("ctau", nl * 16);
+  d.nw = (L + 63) / 64;
+  if (clouds && d.mcica) {
+    d.mask = (uint64_t *)ctx->buf("lw.w.mask", (size_t)kLwNGpt * d.nw * N * 8);
+    d.anymask = (uint64_t *)ctx->buf("lw.w.anymask", (size_t)d.nw * N * 8);
+    if (!d.mask || !d.anymask) ok = false;
+  }
+  const int ntile = (N + 63) / 64;
+  const int nk = d.idrv ? 6 : 4;
+  d.scratch = wd("scratch", (size_t)ntile * 16 * LF_N * L * 64);
+  d.part = wd("part", (size_t)kLwNGpt * nk * nl1);
+  if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
+  if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
+  if (a->memspace == 1) {
+    d.uflx = a->uflx; d.dflx = a->dflx; d.hr = a->hr; d.uflxc = a->uflxc; d.dflxc = a->dflxc; d.hrc = a->hrc;
+    d.duflx_dt = a->duflx_dt; d.duflxc_dt = a->duflxc_dt;
+  } else {
+    d.uflx = wd("o.uflx", nl1); d.dflx = wd("o.dflx", nl1); d.hr = wd("o.hr", nl); d.uflxc = wd("o.uflxc", nl1);
+    d.dflxc = wd("o.dflxc", nl1); d.hrc = wd("o.hrc", nl);
+    if (d.idrv) { d.duflx_dt = wd("o.du", nl1); d.duflxc_dt = wd("o.duc", nl1); }
+  }
+  if (!ok) return ctx->status;
+  d.err = ctx->err_dev;
+  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+
+  const dim3 gcol(ntile), gcl(ntile, L), blk(64);
+  hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
+  if (clouds) {
+    if (!d.mcica) {
+      hipLaunchKernelGGL(lw_cloud_kernel, gcol, blk, 0, s, d, T);
+    } else {
+      hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);
+      if (a->cldfmcl) {
+        const double *cm = in(a->cldfmcl, nl * kLwNGpt, "cldfmcl", true);
+        if (!ok) return ctx->status;
+        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kLwNGpt), blk, 0, s, N, L, kLwNGpt, cm, d.mask, d.nw);
+      } else if (a->irng == 0) {
+        hipLaunchKernelGGL(kiss_mask_kernel, gcol, blk, 0, s, N, L, kLwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err);
+      } else {
+        std::vector<double> cf(nl);
+        if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
+        else cf.assign(a->cldfr, a->cldfr + nl);
+        std::vector<uint64_t> hm;
+        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw);
+        RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
+        RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+      }
+      hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
+    }
+  }
+  launch_lw_solve<1>(d, T, s); launch_lw_solve<2>(d, T, s); launch_lw_solve<3>(d, T, s); launch_lw_solve<4>(d, T, s);
+  launch_lw_solve<5>(d, T, s); launch_lw_solve<6>(d, T, s); launch_lw_solve<7>(d, T, s); launch_lw_solve<8>(d, T, s);
+  launch_lw_solve<9>(d, T, s); launch_lw_solve<10>(d, T, s); launch_lw_solve<11>(d, T, s); launch_lw_solve<12>(d, T, s);
+  launch_lw_solve<13>(d, T, s); launch_lw_solve<14>(d, T, s); launch_lw_solve<15>(d, T, s); launch_lw_solve<16>(d, T, s);
+  hipLaunchKernelGGL(lw_finish_kernel, gcol, blk, 0, s, d, T);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+
+  int herr = 0;
+  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
+  if (a->memspace == 0) {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->uflx, d.uflx, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->dflx, d.dflx, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->uflxc, d.uflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->dflxc, d.dflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->hr, d.hr, nl * 8, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->hrc, d.hrc, nl * 8, hipMemcpyDeviceToHost, s));
+    if (d.idrv) {
+      RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->duflx_dt, d.duflx_dt, nl1 * 8, hipMemcpyDeviceToHost, s));
+      RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->duflxc_dt, d.duflxc_dt, nl1 * 8, hipMemcpyDeviceToHost, s));
+    }
+  }
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (herr) return ctx->fail(herr, "longwave: %s", status_message(herr));
+  ctx->status = 0;
+  return RRTMG_OK;
+}
+
 }  // namespace rrtmg

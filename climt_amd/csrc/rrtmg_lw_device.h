@@ -1,0 +1,940 @@
+// rrtmg_lw_device.h -- RRTMG longwave hot path as per-thread device functions (gfx950).
+//
+// Decomposition (see rrtmg_sw_device.h for the rationale of the wave = 64 columns x one g-point map):
+//   lw_prep_column   one thread per column : inatm + setcoef (interpolation indices/fractions,
+//                    column amounts, pwvcm -> secdiff(band)), laytrop
+//   lw_cloud_column  one thread per column : cldprop (non-McICA; the reference's layer-order dependent
+//                    ncbands bookkeeping is reproduced)   /  lw_cloudmc_layer: cldprmc band optics
+//   lw_solve_thread  one thread per (column, g-point): downward sweep (taumol for the layer, Planck
+//                    terms, no-scattering recurrence; layer state spilled to a [field][layer][lane]
+//                    scratch slab), surface reflection, upward sweep.
+//   lw_finish_column band / g-point integration, flux scaling, heating rates.
+//
+// Reference followed (climt/_lib/rrtmg_lw/): rrtmg_lw_rad.nomcica.f90:80-569,:572-900 (driver, inatm),
+// rrtmg_lw_rad.f90, rrtmg_lw_setcoef.f90:31-415, rrtmg_lw_taumol.f90:31-3147 (taugb1..16),
+// rrtmg_lw_cldprop.f90:31-276, rrtmg_lw_cldprmc.f90:32-254, rrtmg_lw_rtrn.f90:261-587,
+// rrtmg_lw_rtrnmc.f90:32-576.
+#pragma once
+#include "rrtmg_common.h"
+
+namespace rrtmg {
+
+constexpr int kLwNBand = 16;
+constexpr int kLwNGpt = 140;
+
+struct LwBandTab {
+  int ng, gs;
+  int nfraca, nfracb;      // Planck-fraction mixtures (1, 9 / 1, 5)
+  long absa, absb, self, forr, fraca, fracb;
+  long ma[3];              // lower-atmosphere minor-gas tables
+  long mb[2];              // upper-atmosphere minor-gas tables
+  long x[2];               // cross-section tables (ccl4 | cfc11adj, cfc12 | cfc12, cfc22adj)
+};
+
+struct LwTab {
+  const double *t;
+  LwBandTab b[kLwNBand];
+  long preflog, tref, chi_mls, totplnk, totplk16, totplnkderiv, totplk16deriv;
+  long exp_tbl, tau_tbl, tfn_tbl, delwave;
+  long abscld1, absice0, absice1, absice2, absice3, absliq0, absliq1;
+  double heatfac;
+};
+
+struct LwDev {
+  int ncol, nlay;
+  int icld, idrv, inflag, iceflag, liqflag, mcica;
+  Constants k;
+  double fluxfac;
+  // inputs
+  const double *play, *plev, *tlay, *tlev, *tsfc, *h2o, *o3, *co2, *ch4, *n2o, *o2;
+  const double *cfc11, *cfc12, *cfc22, *ccl4, *emis;
+  const double *cldfr, *taucld, *cicewp, *cliqwp, *reice, *reliq, *tauaer;
+  // prep products [lay][col]
+  double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac, *minorfrac;
+  double *scaleminor, *scaleminorn2;
+  double *colh2o, *colco2, *colo3, *coln2o, *colco, *colch4, *colo2, *colbrd, *coldry;
+  double *wx1, *wx2, *wx3, *wx4;
+  int32_t *idx;        // jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<20 | indminor<<24
+  int32_t *laytrop;    // [col]
+  double *secdiff;     // [16][col]
+  // clouds
+  double *ctau;        // [16][lay][col]  (nomcica: taucloud(lay, ib); mcica: per-band cloudy-sub-column tau)
+  int32_t *ncbands;    // [col]
+  uint64_t *mask;      // [140][nw][col]
+  uint64_t *anymask;   // [nw][col]   OR over the sub-columns (icldlyr of rtrnmc)
+  int nw;
+  double *scratch;
+  double *part;        // [140][nk][nlay+1][col], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd
+  int *err;
+  double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
+};
+
+// ------------------------------------------------------------------------------------------
+// inatm (rrtmg_lw_rad.nomcica.f90:744-880) + setcoef indices (rrtmg_lw_setcoef.f90:253-411)
+// ------------------------------------------------------------------------------------------
+RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
+  const int L = d.nlay, N = d.ncol;
+  const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
+  const double amd = 28.9660, amw = 18.0160;
+  const double stpfac = 296.0 / 1013.0;
+  int laytrop = 0;
+  double amttl = 0.0, wvttl = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const long i = (long)l * N + col;
+    const double pz0 = d.plev[i], pz1 = d.plev[i + N];
+    const double pavel = d.play[i], tavel = d.tlay[i];
+    const double v1 = d.h2o[i], v2 = d.co2[i], v3 = d.o3[i], v4 = d.n2o[i], v6 = d.ch4[i], v7 = d.o2[i];
+    const double amm = (1.0 - v1) * amd + v1 * amw;
+    const double coldry = (pz0 - pz1) * 1.e3 * d.k.avogad / (1.e2 * d.k.grav * amm * (1.0 + v1));
+    // summol over molecules 2..7 (wkl(5) = CO is zero)
+    double summol = 0.0;
+    summol = summol + v2; summol = summol + v3; summol = summol + v4; summol = summol + 0.0; summol = summol + v6; summol = summol + v7;
+    const double wbroad = coldry * (1.0 - summol);
+    const double w1 = coldry * v1, w2 = coldry * v2, w3 = coldry * v3, w4 = coldry * v4, w5 = coldry * 0.0, w6 = coldry * v6, w7 = coldry * v7;
+    amttl = amttl + coldry + w1;
+    wvttl = wvttl + w1;
+    d.wx1[i] = coldry * (d.ccl4 ? d.ccl4[i] : 0.0) * 1.e-20;
+    d.wx2[i] = coldry * (d.cfc11 ? d.cfc11[i] : 0.0) * 1.e-20;
+    d.wx3[i] = coldry * (d.cfc12 ? d.cfc12[i] : 0.0) * 1.e-20;
+    d.wx4[i] = coldry * (d.cfc22 ? d.cfc22[i] : 0.0) * 1.e-20;
+
+    const double plog = log(pavel);
+    int jp = (int)(36.0 - 5 * (plog + 0.04));
+    if (jp < 1) jp = 1; else if (jp > 58) jp = 58;
+    const double fp = 5.0 * (preflog[jp - 1] - plog);
+    int jt = (int)(3.0 + (tavel - tref[jp - 1]) / 15.0);
+    if (jt < 1) jt = 1; else if (jt > 4) jt = 4;
+    const double ft = ((tavel - tref[jp - 1]) / 15.0) - (double)(jt - 3);
+    int jt1 = (int)(3.0 + (tavel - tref[jp]) / 15.0);
+    if (jt1 < 1) jt1 = 1; else if (jt1 > 4) jt1 = 4;
+    const double ft1 = ((tavel - tref[jp]) / 15.0) - (double)(jt1 - 3);
+    const double water = w1 / coldry;
+    const double scalefac = pavel * stpfac / tavel;
+    int indself = 0, indfor;
+    double forfac, forfrac, selffac, selffrac = 0.0;
+    if (plog > 4.56) {
+      laytrop++;
+      forfac = scalefac / (1. + water);
+      double factor = (332.0 - tavel) / 36.0;
+      int ifac = (int)factor;
+      indfor = ifac < 1 ? 1 : (ifac > 2 ? 2 : ifac);
+      forfrac = factor - (double)indfor;
+      selffac = water * forfac;
+      factor = (tavel - 188.0) / 7.2;
+      ifac = (int)factor - 7;
+      indself = ifac < 1 ? 1 : (ifac > 9 ? 9 : ifac);
+      selffrac = factor - (double)(indself + 7);
+    } else {
+      forfac = scalefac / (1. + water);
+      const double factor = (tavel - 188.0) / 36.0;
+      indfor = 3;
+      forfrac = factor - 1.0;
+      selffac = water * forfac;
+    }
+    const double scaleminor = pavel / tavel;
+    const double scaleminorn2 = (pavel / tavel) * (wbroad / (coldry + w1));
+    const double fm = (tavel - 180.8) / 7.2;
+    int im = (int)fm;
+    const int indminor = im < 1 ? 1 : (im > 18 ? 18 : im);
+    const double minorfrac = fm - (double)indminor;
+    double colh2o = 1.e-20 * w1, colco2 = 1.e-20 * w2, colo3 = 1.e-20 * w3, coln2o = 1.e-20 * w4;
+    double colco = 1.e-20 * w5, colch4 = 1.e-20 * w6, colo2 = 1.e-20 * w7;
+    if (colco2 == 0.0) colco2 = 1.e-32 * coldry;
+    if (colo3 == 0.0) colo3 = 1.e-32 * coldry;
+    if (coln2o == 0.0) coln2o = 1.e-32 * coldry;
+    if (colco == 0.0) colco = 1.e-32 * coldry;
+    if (colch4 == 0.0) colch4 = 1.e-32 * coldry;
+    const double colbrd = 1.e-20 * wbroad;
+    const double compfp = 1. - fp;
+    d.fac10[i] = compfp * ft;
+    d.fac00[i] = compfp * (1.0 - ft);
+    d.fac11[i] = fp * ft1;
+    d.fac01[i] = fp * (1.0 - ft1);
+    d.selffac[i] = colh2o * selffac; d.forfac[i] = colh2o * forfac;
+    d.selffrac[i] = selffrac; d.forfrac[i] = forfrac; d.minorfrac[i] = minorfrac;
+    d.scaleminor[i] = scaleminor; d.scaleminorn2[i] = scaleminorn2;
+    d.colh2o[i] = colh2o; d.colco2[i] = colco2; d.colo3[i] = colo3; d.coln2o[i] = coln2o; d.colco[i] = colco;
+    d.colch4[i] = colch4; d.colo2[i] = colo2; d.colbrd[i] = colbrd; d.coldry[i] = coldry;
+    d.idx[i] = jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24);
+  }
+  d.laytrop[col] = laytrop;
+  const double wvsh = (amw * wvttl) / (amd * amttl);
+  const double pwvcm = wvsh * (1.e3 * d.plev[col]) / (1.e2 * d.k.grav);
+  // diffusivity angle by band (rrtmg_lw_rtrn.f90:261-269)
+  const double a0[16] = {1.66, 1.55, 1.58, 1.66, 1.54, 1.454, 1.89, 1.33, 1.668, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66, 1.66};
+  const double a1[16] = {0.00, 0.25, 0.22, 0.00, 0.13, 0.446, -0.10, 0.40, -0.006, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+  const double a2[16] = {0.00, -12.0, -11.7, 0.00, -0.72, -0.243, 0.19, -0.062, 0.414, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00, 0.00};
+  for (int b = 0; b < kLwNBand; ++b) {
+    double s;
+    if (b == 0 || b == 3 || b >= 9) {
+      s = 1.66;
+    } else {
+      s = a0[b] + a1[b] * exp(a2[b] * pwvcm);
+      if (s > 1.80) s = 1.80;
+      if (s < 1.50) s = 1.50;
+    }
+    d.secdiff[(long)b * N + col] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// cldprop for one column, non-McICA (rrtmg_lw_cldprop.f90:118-272).  `ncbands` is carried from layer
+// to layer exactly as in the reference: taucloud(lay, 1..ncbands-at-that-time) is written, and the
+// final value selects the band pattern used by rtrn.
+// ------------------------------------------------------------------------------------------
+RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
+  const int L = d.nlay, N = d.ncol;
+  const double *t = T.t;
+  const double cldmin = 1.e-20;
+  const int icb1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
+  int ncbands = 1;
+  for (int l = 0; l < L; ++l) {
+    const long i = (long)l * N + col;
+    for (int ib = 0; ib < 16; ++ib) d.ctau[((long)ib * L + l) * N + col] = 0.0;
+    double tauctot = 0.0;
+    if (d.taucld) for (int ib = 0; ib < 16; ++ib) tauctot = tauctot + d.taucld[i * 16 + ib];
+    const double ciwp = d.cicewp ? d.cicewp[i] : 0.0, clwp = d.cliqwp ? d.cliqwp[i] : 0.0;
+    const double cwp = ciwp + clwp;
+    if (!(d.cldfr[i] >= cldmin && (cwp >= cldmin || tauctot >= cldmin))) continue;
+    if (d.inflag == 0) {
+      ncbands = 16;
+      for (int ib = 0; ib < 16; ++ib) d.ctau[((long)ib * L + l) * N + col] = d.taucld[i * 16 + ib];
+    } else if (d.inflag == 1) {
+      ncbands = 16;
+      for (int ib = 0; ib < 16; ++ib) d.ctau[((long)ib * L + l) * N + col] = t[T.abscld1] * cwp;
+    } else if (d.inflag == 2) {
+      double abscoice[16], abscoliq[16];
+      for (int ib = 0; ib < 16; ++ib) { abscoice[ib] = 0.0; abscoliq[ib] = 0.0; }
+      int iceind = 0, liqind = 0;
+      const double radice = d.reice[i];
+      if (ciwp == 0.0) {
+        abscoice[0] = 0.0; iceind = 0;
+      } else if (d.iceflag == 0) {
+        if (radice < 10.0) report_error(d.err, 11);
+        abscoice[0] = t[T.absice0] + t[T.absice0 + 1] / radice;
+        iceind = 0;
+      } else if (d.iceflag == 1) {
+        if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+        ncbands = 5;
+        for (int ib = 0; ib < 5; ++ib) abscoice[ib] = t[T.absice1 + 2 * ib] + t[T.absice1 + 2 * ib + 1] / radice;
+        iceind = 1;
+      } else if (d.iceflag == 2) {
+        if (radice < 5.0 || radice > 131.0) report_error(d.err, 11);
+        ncbands = 16;
+        const double factor = (radice - 2.0) / 3.0;
+        int index = (int)factor;
+        if (index == 43) index = 42;
+        if (index < 1) index = 1;
+        const double fint = factor - (double)index;
+        for (int ib = 0; ib < 16; ++ib) {
+          const long k = T.absice2 + (index - 1) + 43 * ib;
+          abscoice[ib] = t[k] + fint * (t[k + 1] - (t[k]));
+        }
+        iceind = 2;
+      } else if (d.iceflag == 3) {
+        if (radice < 5.0 || radice > 140.0) report_error(d.err, 11);
+        ncbands = 16;
+        const double factor = (radice - 2.0) / 3.0;
+        int index = (int)factor;
+        if (index == 46) index = 45;
+        if (index < 1) index = 1;
+        const double fint = factor - (double)index;
+        for (int ib = 0; ib < 16; ++ib) {
+          const long k = T.absice3 + (index - 1) + 46 * ib;
+          abscoice[ib] = t[k] + fint * (t[k + 1] - (t[k]));
+        }
+        iceind = 2;
+      }
+      if (clwp == 0.0) {
+        abscoliq[0] = 0.0; liqind = 0;
+        if (iceind == 1) iceind = 2;
+      } else if (d.liqflag == 0) {
+        abscoliq[0] = t[T.absliq0]; liqind = 0;
+        if (iceind == 1) iceind = 2;
+      } else if (d.liqflag == 1) {
+        const double radliq = d.reliq[i];
+        if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+        int index = (int)(radliq - 1.5);
+        if (index == 0) index = 1;
+        if (index == 58) index = 57;
+        if (index < 1) index = 1;
+        if (index > 57) index = 57;
+        const double fint = radliq - 1.5 - (double)index;
+        ncbands = 16;
+        for (int ib = 0; ib < 16; ++ib) {
+          const long k = T.absliq1 + (index - 1) + 58 * ib;
+          abscoliq[ib] = t[k] + fint * (t[k + 1] - (t[k]));
+        }
+        liqind = 2;
+      }
+      for (int ib = 0; ib < ncbands; ++ib) {
+        const int ii = iceind == 0 ? 0 : (iceind == 1 ? icb1[ib] - 1 : ib);
+        const int il = liqind == 0 ? 0 : ib;
+        d.ctau[((long)ib * L + l) * N + col] = ciwp * abscoice[ii] + clwp * abscoliq[il];
+      }
+    }
+  }
+  d.ncbands[col] = ncbands;
+}
+
+// cldprmc band values for one (column, layer): every cloudy sub-column of band ib gets this tau
+// (rrtmg_lw_cldprmc.f90:103-250)
+RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay) {
+  const int L = d.nlay, N = d.ncol;
+  const double *t = T.t;
+  const long i = (long)lay * N + col;
+  const double cldmin = 1.e-20;
+  const int icb1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
+  const double ciwp = d.cicewp ? d.cicewp[i] : 0.0, clwp = d.cliqwp ? d.cliqwp[i] : 0.0;
+  const double cwp = ciwp + clwp;
+  if (d.inflag == 1) report_error(d.err, 20);
+  for (int ib = 0; ib < 16; ++ib) {
+    const double tin = d.taucld ? d.taucld[i * 16 + ib] : 0.0;
+    double tau = tin;
+    if (d.inflag == 2 && (cwp >= cldmin || tin >= cldmin)) {
+      double abscoice = 0.0, abscoliq = 0.0;
+      const double radice = d.reice[i];
+      if (ciwp == 0.0) {
+      } else if (d.iceflag == 0) {
+        if (radice < 10.0) report_error(d.err, 11);
+        abscoice = t[T.absice0] + t[T.absice0 + 1] / radice;
+      } else if (d.iceflag == 1) {
+        if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+        const int jb = icb1[ib] - 1;
+        abscoice = t[T.absice1 + 2 * jb] + t[T.absice1 + 2 * jb + 1] / radice;
+      } else if (d.iceflag == 2 || d.iceflag == 3) {
+        const int nr = d.iceflag == 2 ? 43 : 46;
+        if (radice < 5.0 || radice > (d.iceflag == 2 ? 131.0 : 140.0)) report_error(d.err, 11);
+        const double factor = (radice - 2.0) / 3.0;
+        int index = (int)factor;
+        if (index == nr) index = nr - 1;
+        if (index < 1) index = 1;
+        const double fint = factor - (double)index;
+        const long k = (d.iceflag == 2 ? T.absice2 : T.absice3) + (index - 1) + nr * ib;
+        abscoice = t[k] + fint * (t[k + 1] - (t[k]));
+      }
+      if (clwp == 0.0) {
+      } else if (d.liqflag == 0) {
+        abscoliq = t[T.absliq0];
+      } else if (d.liqflag == 1) {
+        const double radliq = d.reliq[i];
+        if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+        int index = (int)(radliq - 1.5);
+        if (index == 0) index = 1;
+        if (index == 58) index = 57;
+        if (index < 1) index = 1;
+        if (index > 57) index = 57;
+        const double fint = radliq - 1.5 - (double)index;
+        const long k = T.absliq1 + (index - 1) + 58 * ib;
+        abscoliq = t[k] + fint * (t[k + 1] - (t[k]));
+      }
+      tau = ciwp * abscoice + clwp * abscoliq;
+    }
+    d.ctau[((long)ib * L + lay) * N + col] = tau;
+  }
+}
+
+// OR of the sub-column masks: icldlyr of rtrnmc (rrtmg_lw_rtrnmc.f90:298-312)
+RRTMG_HD void lw_anymask_column(const LwDev &d, int col) {
+  for (int w = 0; w < d.nw; ++w) {
+    uint64_t m = 0;
+    for (int g = 0; g < kLwNGpt; ++g) m |= d.mask[((long)g * d.nw + w) * d.ncol + col];
+    d.anymask[(long)w * d.ncol + col] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// taumol pieces
+// ------------------------------------------------------------------------------------------
+struct LwLayerIn {
+  double fac00, fac01, fac10, fac11, selffac, selffrac, forfac, forfrac, minorfrac, scaleminor, scaleminorn2;
+  double colh2o, colco2, colo3, coln2o, colco, colch4, colo2, colbrd, coldry, pavel, wx1, wx2, wx3, wx4;
+  int jp, jt, jt1, indself, indfor, indminor;
+};
+
+RRTMG_HD void lw_load_layer(const LwDev &d, long i, LwLayerIn &s) {
+  s.fac00 = d.fac00[i]; s.fac01 = d.fac01[i]; s.fac10 = d.fac10[i]; s.fac11 = d.fac11[i];
+  s.selffac = d.selffac[i]; s.selffrac = d.selffrac[i]; s.forfac = d.forfac[i]; s.forfrac = d.forfrac[i];
+  s.minorfrac = d.minorfrac[i]; s.scaleminor = d.scaleminor[i]; s.scaleminorn2 = d.scaleminorn2[i];
+  s.colh2o = d.colh2o[i]; s.colco2 = d.colco2[i]; s.colo3 = d.colo3[i]; s.coln2o = d.coln2o[i]; s.colco = d.colco[i];
+  s.colch4 = d.colch4[i]; s.colo2 = d.colo2[i]; s.colbrd = d.colbrd[i]; s.coldry = d.coldry[i]; s.pavel = d.play[i];
+  s.wx1 = d.wx1[i]; s.wx2 = d.wx2[i]; s.wx3 = d.wx3[i]; s.wx4 = d.wx4[i];
+  const int p = d.idx[i];
+  s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xf; s.indfor = (p >> 20) & 0xf;
+  s.indminor = (p >> 24) & 0x1f;
+}
+
+struct LwSpec { double speccomb, specparm, fs; int js; };
+RRTMG_HD LwSpec lw_spec(double colx, double rat, double coly, double mult) {
+  LwSpec r;
+  r.speccomb = colx + rat * coly;
+  r.specparm = colx / r.speccomb;
+  const double oneminus = 1.0 - 1.e-6;
+  if (r.specparm >= oneminus) r.specparm = oneminus;
+  const double specmult = mult * r.specparm;
+  r.js = 1 + (int)specmult;
+  r.fs = specmult - (double)(int)specmult;
+  return r;
+}
+
+// chi_mls(m, j) with 1-based (m, j): reference mixing ratios (rrlw_ref)
+RRTMG_HD double lw_chi(const LwTab &T, int m, int j) { return T.t[T.chi_mls + (m - 1) + 7 * (j - 1)]; }
+
+// lower-atmosphere binary-species major term with the 3-point end-zone blend
+// (pattern at rrtmg_lw_taumol.f90:550-609 / :622-668); k -> table of this g-point, ind 0-based index
+// of (js, jt, jp) ; f0/f1 = (fac00, fac10) for the jp side or (fac01, fac11) for the jp+1 side.
+RRTMG_HD double lw_major_lower(const double *k, int ind, const LwSpec &sp, double f0, double f1) {
+  if (sp.specparm < 0.125) {
+    const double p = sp.fs - 1;
+    const double p2 = p * p, p4 = p2 * p2;
+    const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+    return sp.speccomb * (fk0 * f0 * k[ind] + fk1 * f0 * k[ind + 1] + fk2 * f0 * k[ind + 2] + fk0 * f1 * k[ind + 9] +
+                          fk1 * f1 * k[ind + 10] + fk2 * f1 * k[ind + 11]);
+  } else if (sp.specparm > 0.875) {
+    const double p = -sp.fs;
+    const double p2 = p * p, p4 = p2 * p2;
+    const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
+    return sp.speccomb * (fk2 * f0 * k[ind - 1] + fk1 * f0 * k[ind] + fk0 * f0 * k[ind + 1] + fk2 * f1 * k[ind + 8] +
+                          fk1 * f1 * k[ind + 9] + fk0 * f1 * k[ind + 10]);
+  }
+  return sp.speccomb * ((1.0 - sp.fs) * f0 * k[ind] + sp.fs * f0 * k[ind + 1] + (1.0 - sp.fs) * f1 * k[ind + 9] +
+                        sp.fs * f1 * k[ind + 10]);
+}
+// upper-atmosphere binary-species term (4 points, nspb = 5)
+RRTMG_HD double lw_major_upper(const double *k, int ind, const LwSpec &sp, double f0, double f1) {
+  return sp.speccomb * ((1.0 - sp.fs) * f0 * k[ind] + sp.fs * f0 * k[ind + 1] + (1.0 - sp.fs) * f1 * k[ind + 5] + sp.fs * f1 * k[ind + 6]);
+}
+RRTMG_HD double lw_m4(const double *k, int i0, int i1, const LwLayerIn &s) {
+  return s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1];
+}
+RRTMG_HD double lw_tauself(const double *selfref, const LwLayerIn &s) {
+  const double a = selfref[s.indself - 1], b = selfref[s.indself];
+  return s.selffac * (a + s.selffrac * (b - a));
+}
+RRTMG_HD double lw_taufor(const double *forref, const LwLayerIn &s) {
+  const double a = forref[s.indfor - 1], b = forref[s.indfor];
+  return s.forfac * (a + s.forfrac * (b - a));
+}
+// minor-gas coefficient, temperature-interpolated: table (19, ng)
+RRTMG_HD double lw_minor1(const double *tab, int ig, const LwLayerIn &s) {
+  const double *m = tab + 19 * ig + (s.indminor - 1);
+  return m[0] + s.minorfrac * (m[1] - m[0]);
+}
+// minor-gas coefficient, (mixture, temperature)-interpolated: table (nm, 19, ng)
+RRTMG_HD double lw_minor2(const double *tab, int nm, int ig, int jm, double fm, const LwLayerIn &s) {
+  const double *m = tab + (long)nm * 19 * ig + (long)nm * (s.indminor - 1) + (jm - 1);
+  const double m1 = m[0] + fm * (m[1] - m[0]);
+  const double m2 = m[nm] + fm * (m[nm + 1] - m[nm]);
+  return m1 + s.minorfrac * (m2 - m1);
+}
+// Planck fraction interpolated in the reference mixture: table (ng, nmix)
+RRTMG_HD double lw_frac2(const double *tab, int ng, int ig, const LwSpec &pl) {
+  const double a = tab[ig + ng * (pl.js - 1)], b = tab[ig + ng * pl.js];
+  return a + pl.fs * (b - a);
+}
+// "too abundant" minor-gas column adjustment: adjfac = a + (rat - a)**e  
+RRTMG_HD double lw_adjcol(double col, double coldry, double chiref, double e20, double thresh, double a, double e, double chimul) {
+  const double chi = col / coldry;
+  const double rat = e20 * chi / chiref;
+  if (rat > thresh) {
+    const double adjfac = a + pow(rat - a, e);
+    return adjfac * chimul * coldry * 1.e-20;
+  }
+  return col;
+}
+
+constexpr double kE20f = (double)1.e20f;   // `1.e20` default-real literals at rrtmg_lw_taumol.f90:715,:1462,:1618
+
+// gas optical depth and Planck fraction of one (layer, g-point) of band BAND (1..16)
+template <int BAND>
+RRTMG_HD double lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig, double &fracs) {
+  const LwBandTab &B = T.b[BAND - 1];
+  const double *t = T.t;
+  constexpr int nspa_[16] = {1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9};
+  constexpr int nspb_[16] = {1, 1, 5, 5, 5, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0, 0};
+  constexpr int nspa = nspa_[BAND - 1], nspb = nspb_[BAND - 1];
+  const double *absa = t + B.absa + (long)ig * 65 * nspa;
+  // band 16 has a kb table but nspb(16) = 0 in lwdatinit, so the reference's index
+  // ((jp-13)*5+(jt-1))*nspb(16) + 1 collapses to 1 for every upper layer (rrtmg_lw_taumol.f90 taugb16)
+  const double *absb = t + B.absb + (long)ig * 235 * (BAND == 16 ? 1 : nspb);
+  const double *selfref = t + B.self + (long)ig * 10;
+  const double *forref = t + B.forr + (long)ig * 4;
+  const int ng = B.ng;
+  double taug = 0.0;
+  const int i0s = ((s.jp - 1) * 5 + (s.jt - 1)), i1s = (s.jp * 5 + (s.jt1 - 1));         // lower, nspa = 1
+  const int u0s = ((s.jp - 13) * 5 + (s.jt - 1)) * (BAND == 16 ? 0 : 1), u1s = ((s.jp - 12) * 5 + (s.jt1 - 1)) * (BAND == 16 ? 0 : 1);  // upper, nspb = 1
+  // species pair of the binary bands: x = key species 1, y = key species 2, rat = chi_x/chi_y at jp, jp+1
+  auto chirat = [&](int mx, int my, int j) { return lw_chi(T, mx, j) / lw_chi(T, my, j); };
+
+  if constexpr (BAND == 1) {
+    const double scalen2 = s.colbrd * s.scaleminorn2;
+    if (lower) {
+      double corradj = 1.;
+      if (s.pavel < 250.0) corradj = 1.0 - 0.15 * (250.0 - s.pavel) / 154.4;
+      const double taun2 = scalen2 * lw_minor1(t + B.ma[0], ig, s);
+      taug = corradj * (s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + taun2);
+      fracs = t[B.fraca + ig];
+    } else {
+      const double corradj = 1.0 - 0.15 * (s.pavel / 95.6);
+      const double taun2 = scalen2 * lw_minor1(t + B.mb[0], ig, s);
+      taug = corradj * (s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s) + taun2);
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 2) {
+    if (lower) {
+      const double corradj = 1.0 - .05 * (s.pavel - 100.0) / 900.0;
+      taug = corradj * (s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s));
+      fracs = t[B.fraca + ig];
+    } else {
+      taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s);
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 3) {
+    // h2o/co2; minor n2o
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 3), s.colco2, 8.0), pl = lw_spec(s.colh2o, chirat(1, 2, 9), s.colco2, 8.0);
+      const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), 1.e20, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
+      const double absn2o = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcoln2o * absn2o;
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 4.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 13), s.colco2, 4.0), pl = lw_spec(s.colh2o, chirat(1, 2, 13), s.colco2, 4.0);
+      const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), kE20f, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
+      const double absn2o = lw_minor2(t + B.mb[0], 5, ig, sm.js, sm.fs, s);
+      taug = lw_major_upper(absb, u0s * 5 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_upper(absb, u1s * 5 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_taufor(forref, s) + adjcoln2o * absn2o;
+      fracs = lw_frac2(t + B.fracb, ng, ig, pl);
+    }
+  } else if constexpr (BAND == 4 || BAND == 5) {
+    // lower h2o/co2 ; upper o3/co2.  band 5: minor o3 (lower), ccl4 (both)
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 2, BAND == 4 ? 11 : 5), s.colco2, 8.0);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s);
+      if constexpr (BAND == 5) {
+        const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 7), s.colco2, 8.0);
+        const double abso3 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+        taug = taug + abso3 * s.colo3 + s.wx1 * t[B.x[0] + ig];
+      }
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      const LwSpec sp = lw_spec(s.colo3, chirat(3, 2, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colo3, chirat(3, 2, s.jp + 1), s.colco2, 4.0);
+      const LwSpec pl = lw_spec(s.colo3, chirat(3, 2, BAND == 4 ? 13 : 43), s.colco2, 4.0);
+      taug = lw_major_upper(absb, u0s * 5 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_upper(absb, u1s * 5 + sp1.js - 1, sp1, s.fac01, s.fac11);
+      if constexpr (BAND == 5) taug = taug + s.wx1 * t[B.x[0] + ig];
+      fracs = lw_frac2(t + B.fracb, ng, ig, pl);
+      if constexpr (BAND == 4) {
+        // empirical stratospheric scalings, default-real literals (rrtmg_lw_taumol.f90:1009-1015)
+        const double sc[7] = {(double)0.92f, (double)0.88f, (double)1.07f, (double)1.1f, (double)0.99f, (double)0.88f, (double)0.943f};
+        if (ig >= 7) taug = taug * sc[ig - 7];
+      }
+    }
+  } else if constexpr (BAND == 6) {
+    if (lower) {
+      const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), 1.e20, 3.0, 2.0, 0.77, lw_chi(T, 2, s.jp + 1));
+      const double absco2 = lw_minor1(t + B.ma[0], ig, s);
+      taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 +
+             s.wx2 * t[B.x[0] + ig] + s.wx3 * t[B.x[1] + ig];
+    } else {
+      taug = 0.0 + s.wx2 * t[B.x[0] + ig] + s.wx3 * t[B.x[1] + ig];
+    }
+    fracs = t[B.fraca + ig];
+  } else if constexpr (BAND == 7) {
+    // lower h2o/o3, minor co2 ; upper o3, minor co2
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 3, s.jp), s.colo3, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 3, s.jp + 1), s.colo3, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 3, 3), s.colo3, 8.0), pl = lw_spec(s.colh2o, chirat(1, 3, 3), s.colo3, 8.0);
+      const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), kE20f, 3.0, 3.0, 0.79, lw_chi(T, 2, s.jp + 1));
+      const double absco2 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2;
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), kE20f, 3.0, 2.0, 0.79, lw_chi(T, 2, s.jp + 1));
+      const double absco2 = lw_minor1(t + B.mb[0], ig, s);
+      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2;
+      fracs = t[B.fracb + ig];
+      const double sc[6] = {0.92, 0.88, 1.07, 1.1, 0.99, 0.855};   // rrtmg_lw_taumol.f90:1645-1650 (_rb literals)
+      if (ig >= 5 && ig <= 10) taug = taug * sc[ig - 5];
+    }
+  } else if constexpr (BAND == 8) {
+    const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), 1.e20, 3.0, 2.0, 0.65, lw_chi(T, 2, s.jp + 1));
+    if (lower) {
+      const double absco2 = lw_minor1(t + B.ma[0], ig, s), abso3 = lw_minor1(t + B.ma[1], ig, s), absn2o = lw_minor1(t + B.ma[2], ig, s);
+      taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 + s.colo3 * abso3 +
+             s.coln2o * absn2o + s.wx3 * t[B.x[0] + ig] + s.wx4 * t[B.x[1] + ig];
+      fracs = t[B.fraca + ig];
+    } else {
+      const double absco2 = lw_minor1(t + B.mb[0], ig, s), absn2o = lw_minor1(t + B.mb[1], ig, s);
+      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2 + s.coln2o * absn2o + s.wx3 * t[B.x[0] + ig] + s.wx4 * t[B.x[1] + ig];
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 9) {
+    const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), 1.e20, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 6, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 6, s.jp + 1), s.colch4, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 6, 3), s.colch4, 8.0), pl = lw_spec(s.colh2o, chirat(1, 6, 9), s.colch4, 8.0);
+      const double absn2o = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcoln2o * absn2o;
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      const double absn2o = lw_minor1(t + B.mb[0], ig, s);
+      taug = s.colch4 * lw_m4(absb, u0s, u1s, s) + adjcoln2o * absn2o;
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 10) {
+    if (lower) {
+      taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s);
+      fracs = t[B.fraca + ig];
+    } else {
+      taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s);
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 11) {
+    const double scaleo2 = s.colo2 * s.scaleminor;
+    if (lower) {
+      const double tauo2 = scaleo2 * lw_minor1(t + B.ma[0], ig, s);
+      taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + tauo2;
+      fracs = t[B.fraca + ig];
+    } else {
+      const double tauo2 = scaleo2 * lw_minor1(t + B.mb[0], ig, s);
+      taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s) + tauo2;
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 12) {
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 2, 10), s.colco2, 8.0);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s);
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      taug = 0.0; fracs = 0.0;
+    }
+  } else if constexpr (BAND == 13) {
+    // lower h2o/n2o, minor co2 and co ; upper o3 minor only
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 4, s.jp), s.coln2o, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 4, s.jp + 1), s.coln2o, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 4, 1), s.coln2o, 8.0), sm3 = lw_spec(s.colh2o, chirat(1, 4, 3), s.coln2o, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 4, 5), s.coln2o, 8.0);
+      // adjcolco2 = adjfac*3.55e-4*coldry*1e-20 with a default-real 3.55e-4 (rrtmg_lw_taumol.f90:2479)
+      const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, 3.55e-4, 1.e20, 3.0, 2.0, 0.68, (double)3.55e-4f);
+      const double absco2 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      const double absco = lw_minor2(t + B.ma[1], 9, ig, sm3.js, sm3.fs, s);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 + s.colco * absco;
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      const double abso3 = lw_minor1(t + B.mb[0], ig, s);
+      taug = s.colo3 * abso3;
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 14) {
+    if (lower) {
+      taug = s.colco2 * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s);
+      fracs = t[B.fraca + ig];
+    } else {
+      taug = s.colco2 * lw_m4(absb, u0s, u1s, s);
+      fracs = t[B.fracb + ig];
+    }
+  } else if constexpr (BAND == 15) {
+    // lower n2o/co2, minor n2 ; nothing above
+    if (lower) {
+      const LwSpec sp = lw_spec(s.coln2o, chirat(4, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.coln2o, chirat(4, 2, s.jp + 1), s.colco2, 8.0);
+      const LwSpec sm = lw_spec(s.coln2o, chirat(4, 2, 1), s.colco2, 8.0), pl = lw_spec(s.coln2o, chirat(4, 2, 1), s.colco2, 8.0);
+      const double scalen2 = s.colbrd * s.scaleminor;
+      const double taun2 = scalen2 * lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s) + taun2;
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      taug = 0.0; fracs = 0.0;
+    }
+  } else {  // 16
+    if (lower) {
+      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 6, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 6, s.jp + 1), s.colch4, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 6, 6), s.colch4, 8.0);
+      taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
+             lw_tauself(selfref, s) + lw_taufor(forref, s);
+      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+    } else {
+      taug = s.colch4 * lw_m4(absb, u0s, u1s, s);
+      fracs = t[B.fracb + ig];
+    }
+  }
+  return taug;
+}
+
+// Planck function integrated over band ib (0-based) at temperature tt: linear interpolation in
+// totplnk(181,16) (rrtmg_lw_setcoef.f90:147-250, istart = 1)
+RRTMG_HD double lw_planck(const LwTab &T, int ib, double tt) {
+  int ind = (int)(tt - 159.0);
+  if (ind < 1) ind = 1; else if (ind > 180) ind = 180;
+  const double frac = tt - 159.0 - (double)ind;
+  const double *p = T.t + T.totplnk + 181 * ib + (ind - 1);
+  return p[0] + frac * (p[1] - p[0]);
+}
+RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
+  int ind = (int)(tt - 159.0);
+  if (ind < 1) ind = 1; else if (ind > 180) ind = 180;
+  const double frac = tt - 159.0 - (double)ind;
+  const double *p = T.t + T.totplnkderiv + 181 * ib + (ind - 1);
+  return p[0] + frac * (p[1] - p[0]);
+}
+
+enum { LF_ATRANS = 0, LF_BBUGAS, LF_ATOT, LF_BBUTOT, LF_N };
+
+// One (column, g-point): rtrn / rtrnmc for this g-point (rrtmg_lw_rtrn.f90:324-525).
+template <int BAND>
+RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, double *scr, long stride) {
+  const int L = d.nlay, N = d.ncol;
+  const int ib = BAND - 1;
+  const int iw = T.b[ib].gs + ig;
+  const double *t = T.t;
+  const double *exp_tbl = t + T.exp_tbl, *tau_tbl = t + T.tau_tbl, *tfn_tbl = t + T.tfn_tbl;
+  const double rec_6 = 0.166667;
+  const int laytrop = d.laytrop[col];
+  const double secd = d.secdiff[(long)ib * N + col];
+  const int nk = d.idrv ? 6 : 4;
+  auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
+  auto P = [&](int k, int lev) -> double & { return d.part[(((long)iw * nk + k) * (L + 1) + lev) * N + col]; };
+
+  // cloud bookkeeping
+  const bool clouds = d.icld >= 1 && d.cldfr != nullptr;
+  uint64_t mw[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0};
+  int cb = 0;           // cloud band index used for odcld / efclfrac (non-McICA)
+  double secd_cb = secd;
+  if (clouds) {
+    if (d.mcica) {
+      for (int w = 0; w < d.nw && w < 4; ++w) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; aw[w] = d.anymask[(long)w * N + col]; }
+    } else {
+      const int ncb = d.ncbands[col];
+      const int ipat1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
+      cb = ncb == 1 ? 0 : (ncb == 5 ? ipat1[ib] - 1 : ib);
+      secd_cb = d.secdiff[(long)cb * N + col];   // odcld(lay,ib) = secdiff(ib)*taucloud(lay,ib): cloud-band index
+    }
+  }
+
+  // ---- downward sweep, lev = L .. 1 ---------------------------------------------------------
+  double radld = 0.0, radclrd = 0.0;
+  int iclddn = 0;
+  double plfrac_bot = 0.0;
+  P(1, L) = 0.0;
+  P(3, L) = 0.0;
+  double tz_up = d.tlev[(long)L * N + col];
+  for (int lev = L; lev >= 1; --lev) {
+    const int l = lev - 1;
+    const long i = (long)l * N + col;
+    LwLayerIn s;
+    lw_load_layer(d, i, s);
+    double plfrac;
+    const double taug = lw_taug<BAND>(T, s, lev <= laytrop, ig, plfrac);
+    const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
+    const double taut = taug + taua;
+    const double tz_dn = d.tlev[i];
+    const double blay = lw_planck(T, ib, d.tlay[i]);
+    const double dplankup = lw_planck(T, ib, tz_up) - blay;
+    const double dplankdn = lw_planck(T, ib, tz_dn) - blay;
+    tz_up = tz_dn;
+    double odepth = secd * taut;
+    if (odepth < 0.0) odepth = 0.0;
+    // is this a cloudy layer for the recurrence?
+    bool icldlyr = false;
+    double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
+    if (clouds) {
+      if (d.mcica) {
+        icldlyr = (aw[l >> 6] >> (l & 63)) & 1ull;
+        if ((mw[l >> 6] >> (l & 63)) & 1ull) {
+          cfrac = 1.0;
+          odcld = secd * d.ctau[((long)ib * L + l) * N + col];
+          const double transcld = exp(-odcld);
+          efclfrac = (1.0 - transcld) * cfrac;
+        }
+      } else {
+        cfrac = d.cldfr[i];
+        if (cfrac >= 1.e-6) {
+          icldlyr = true;
+          odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
+          const double transcld = exp(-odcld);
+          efclfrac = (1. - transcld) * cfrac;
+        }
+      }
+    }
+    double atrans, bbd, bbugas;
+    if (icldlyr) {
+      iclddn = 1;
+      double odtot = odepth + odcld;
+      double gassrc, atot, bbdtot, bbutot;
+      if (odtot < 0.06) {
+        atrans = odepth - 0.5 * odepth * odepth;
+        const double odepth_rec = rec_6 * odepth;
+        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans;
+        atot = odtot - 0.5 * odtot * odtot;
+        const double odtot_rec = rec_6 * odtot;
+        bbdtot = plfrac * (blay + dplankdn * odtot_rec);
+        bbd = plfrac * (blay + dplankdn * odepth_rec);
+        bbugas = plfrac * (blay + dplankup * odepth_rec);
+        bbutot = plfrac * (blay + dplankup * odtot_rec);
+      } else if (odepth <= 0.06) {
+        atrans = odepth - 0.5 * odepth * odepth;
+        const double odepth_rec = rec_6 * odepth;
+        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans;
+        odtot = odepth + odcld;
+        const double tblind = odtot / (kBpade + odtot);
+        const int ittot = (int)(kTblInt * tblind + 0.5);
+        const double tfactot = tfn_tbl[ittot];
+        bbdtot = plfrac * (blay + tfactot * dplankdn);
+        bbd = plfrac * (blay + dplankdn * odepth_rec);
+        atot = 1.0 - exp_tbl[ittot];
+        bbugas = plfrac * (blay + dplankup * odepth_rec);
+        bbutot = plfrac * (blay + tfactot * dplankup);
+      } else {
+        double tblind = odepth / (kBpade + odepth);
+        const int itgas = (int)(kTblInt * tblind + 0.5);
+        odepth = tau_tbl[itgas];
+        atrans = 1.0 - exp_tbl[itgas];
+        const double tfacgas = tfn_tbl[itgas];
+        gassrc = atrans * plfrac * (blay + tfacgas * dplankdn);
+        odtot = odepth + odcld;
+        tblind = odtot / (kBpade + odtot);
+        const int ittot = (int)(kTblInt * tblind + 0.5);
+        const double tfactot = tfn_tbl[ittot];
+        bbdtot = plfrac * (blay + tfactot * dplankdn);
+        bbd = plfrac * (blay + tfacgas * dplankdn);
+        atot = 1.0 - exp_tbl[ittot];
+        bbugas = plfrac * (blay + tfacgas * dplankup);
+        bbutot = plfrac * (blay + tfactot * dplankup);
+      }
+      radld = radld - radld * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
+      S(LF_ATOT, l) = atot;
+      S(LF_BBUTOT, l) = bbutot;
+    } else {
+      if (odepth <= 0.06) {
+        atrans = odepth - 0.5 * odepth * odepth;
+        odepth = rec_6 * odepth;
+        bbd = plfrac * (blay + dplankdn * odepth);
+        bbugas = plfrac * (blay + dplankup * odepth);
+      } else {
+        const double tblind = odepth / (kBpade + odepth);
+        const int itr = (int)(kTblInt * tblind + 0.5);
+        const double transc = exp_tbl[itr];
+        atrans = 1.0 - transc;
+        const double tausfac = tfn_tbl[itr];
+        bbd = plfrac * (blay + tausfac * dplankdn);
+        bbugas = plfrac * (blay + tausfac * dplankup);
+      }
+      radld = radld + (bbd - radld) * atrans;
+    }
+    S(LF_ATRANS, l) = atrans;
+    S(LF_BBUGAS, l) = bbugas;
+    P(1, lev - 1) = radld;
+    if (iclddn == 1) {
+      radclrd = radclrd + (bbd - radclrd) * atrans;
+    } else {
+      radclrd = radld;
+    }
+    P(3, lev - 1) = radclrd;
+    plfrac_bot = plfrac;
+  }
+
+  // ---- surface ------------------------------------------------------------------------------
+  const double semiss = d.emis[(long)ib * N + col];
+  const double tbound = d.tsfc[col];
+  const double plankbnd = semiss * lw_planck(T, ib, tbound);
+  const double rad0 = plfrac_bot * plankbnd;
+  const double reflect = 1.0 - semiss;
+  double radlu = rad0 + reflect * radld;
+  double radclru = rad0 + reflect * radclrd;
+  P(0, 0) = radlu;
+  P(2, 0) = radclru;
+  double d_radlu_dt = 0.0, d_radclru_dt = 0.0;
+  if (d.idrv) {
+    const double d_rad0_dt = plfrac_bot * (semiss * lw_planck_deriv(T, ib, tbound));
+    d_radlu_dt = d_rad0_dt; d_radclru_dt = d_rad0_dt;
+    P(4, 0) = d_radlu_dt; P(5, 0) = d_radclru_dt;
+  }
+
+  // ---- upward sweep ---------------------------------------------------------------------------
+  for (int lev = 1; lev <= L; ++lev) {
+    const int l = lev - 1;
+    const double atrans = S(LF_ATRANS, l), bbugas = S(LF_BBUGAS, l);
+    bool icldlyr = false;
+    double cfrac = 0.0, efclfrac = 0.0;
+    if (clouds) {
+      if (d.mcica) {
+        icldlyr = (aw[l >> 6] >> (l & 63)) & 1ull;
+        if ((mw[l >> 6] >> (l & 63)) & 1ull) {
+          cfrac = 1.0;
+          const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
+          efclfrac = (1.0 - exp(-odcld)) * cfrac;
+        }
+      } else {
+        cfrac = d.cldfr[(long)l * N + col];
+        if (cfrac >= 1.e-6) {
+          icldlyr = true;
+          const double odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
+          efclfrac = (1. - exp(-odcld)) * cfrac;
+        }
+      }
+    }
+    if (icldlyr) {
+      const double atot = S(LF_ATOT, l), bbutot = S(LF_BBUTOT, l);
+      const double gassrc = bbugas * atrans;
+      radlu = radlu - radlu * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
+      if (d.idrv) d_radlu_dt = d_radlu_dt * cfrac * (1.0 - atot) + d_radlu_dt * (1.0 - cfrac) * (1.0 - atrans);
+    } else {
+      radlu = radlu + (bbugas - radlu) * atrans;
+      if (d.idrv) d_radlu_dt = d_radlu_dt * (1.0 - atrans);
+    }
+    P(0, lev) = radlu;
+    if (iclddn == 1) {
+      radclru = radclru + (bbugas - radclru) * atrans;
+      if (d.idrv) d_radclru_dt = d_radclru_dt * (1.0 - atrans);
+    } else {
+      radclru = radlu;
+      if (d.idrv) d_radclru_dt = d_radlu_dt;
+    }
+    P(2, lev) = radclru;
+    if (d.idrv) { P(4, lev) = d_radlu_dt; P(5, lev) = d_radclru_dt; }
+  }
+}
+
+// band / g-point integration and heating rates (rrtmg_lw_rtrn.f90:528-585)
+RRTMG_HD void lw_finish_column(const LwDev &d, const LwTab &T, int col) {
+  const int L = d.nlay, N = d.ncol;
+  const int nk = d.idrv ? 6 : 4;
+  const double wtdiff = 0.5;
+  const double *delwave = T.t + T.delwave;
+  double fnet_p = 0.0, fnetc_p = 0.0, pz_p = 0.0;
+  for (int lev = 0; lev <= L; ++lev) {
+    double tot[6] = {0, 0, 0, 0, 0, 0};
+    for (int b = 0; b < kLwNBand; ++b) {
+      double acc[6] = {0, 0, 0, 0, 0, 0};
+      for (int g = 0; g < T.b[b].ng; ++g) {
+        const int iw = T.b[b].gs + g;
+        for (int k = 0; k < nk; ++k) acc[k] = acc[k] + d.part[(((long)iw * nk + k) * (L + 1) + lev) * N + col];
+      }
+      for (int k = 0; k < 4; ++k) tot[k] = tot[k] + (acc[k] * wtdiff) * delwave[b];
+      if (d.idrv) for (int k = 4; k < 6; ++k) tot[k] = tot[k] + (acc[k] * wtdiff) * delwave[b] * d.fluxfac;
+    }
+    const long o = (long)lev * N + col;
+    const double uf = tot[0] * d.fluxfac, df = tot[1] * d.fluxfac, ucf = tot[2] * d.fluxfac, dcf = tot[3] * d.fluxfac;
+    d.uflx[o] = uf; d.dflx[o] = df; d.uflxc[o] = ucf; d.dflxc[o] = dcf;
+    if (d.idrv) { d.duflx_dt[o] = tot[4]; d.duflxc_dt[o] = tot[5]; }
+    const double fnet = uf - df, fnetc = ucf - dcf;
+    const double pz = d.plev[o];
+    if (lev > 0) {
+      const long ol = (long)(lev - 1) * N + col;
+      d.hr[ol] = T.heatfac * (fnet_p - fnet) / (pz_p - pz);
+      d.hrc[ol] = T.heatfac * (fnetc_p - fnetc) / (pz_p - pz);
+    }
+    fnet_p = fnet; fnetc_p = fnetc; pz_p = pz;
+  }
+}
+
+}  // namespace rrtmg

@@ -10,6 +10,7 @@
 #include "rrtmg_ctx.h"
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
+#include "rrtmg_mcica_kernels.h"
 
 namespace rrtmg {
 
@@ -48,36 +49,6 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
     }
     const long o = ((long)ib * L + lay) * N + col;
     ta[o] = ztaua; om[o] = zomga; as[o] = zasya;
-  }
-}
-
-__global__ void __launch_bounds__(64) kiss_mask_kernel(int ncol, int nlay, int nsub, int icld, int seed, const double *play,
-                                                       const double *cldfr, uint64_t *mask, int nw, int *err) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < ncol) kiss_mask_column(ncol, nlay, nsub, icld, seed, play, cldfr, mask, nw, err, col);
-}
-
-// externally supplied cldfmcl [lay][col][nsub] (0/1 doubles) -> bit mask
-__global__ void __launch_bounds__(64) mask_from_cldfmcl_kernel(int ncol, int nlay, int nsub, const double *cldfmcl, uint64_t *mask, int nw) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  const int g = blockIdx.y;
-  if (col >= ncol) return;
-  for (int w = 0; w < nw; ++w) {
-    uint64_t m = 0;
-    for (int l = w * 64; l < nlay && l < (w + 1) * 64; ++l)
-      if (cldfmcl[((long)l * ncol + col) * nsub + g] > 1.e-12) m |= 1ull << (l & 63);
-    mask[((long)g * nw + w) * ncol + col] = m;
-  }
-}
-
-// bit mask -> cldfmcl doubles (for the stand-alone sub-column generator entry point)
-__global__ void __launch_bounds__(64) cldfmcl_from_mask_kernel(int ncol, int nlay, int nsub, const uint64_t *mask, int nw, double *cldfmcl) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  const int g = blockIdx.y;
-  if (col >= ncol) return;
-  for (int l = 0; l < nlay; ++l) {
-    const uint64_t m = mask[((long)g * nw + (l >> 6)) * ncol + col];
-    cldfmcl[((long)l * ncol + col) * nsub + g] = ((m >> (l & 63)) & 1ull) ? 1.0 : 0.0;
   }
 }
 

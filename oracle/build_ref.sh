@@ -63,6 +63,8 @@ build_lw() {
   for m in $mods $code; do compile lw "$S" "$m" -O2; done
   # our own file: empty lw_kgb01..16 (data blob missing from the reference checkout)
   (cd "$OUT/lw" && "$FC" -fPIC -O0 -c "$HERE/lw_kg_stub.f90" -o "$OUT/lw/lw_kg_stub.o" -module-dir "$OUT/lw")
+  # our own stage driver (inatm -> setcoef -> taumol of the reference) for band-by-band checks
+  (cd "$OUT/lw" && "$FC" -fPIC -O2 -c "$HERE/lw_stage_shim.f90" -o "$OUT/lw/lw_stage_shim.o" -module-dir "$OUT/lw" -I"$OUT/lw")
   "$FC" -shared -fPIC -o "$OUT/librrtmg_lw_ref.so" "$OUT"/lw/*.o
   echo "built $OUT/librrtmg_lw_ref.so"
 }

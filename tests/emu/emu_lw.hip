@@ -1,0 +1,161 @@
+// TEST INFRASTRUCTURE ONLY -- host emulation of the longwave DEVICE functions (see emu_sw.hip).
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../climt_amd/csrc/rrtmg_lw_device.h"
+#include "../../climt_amd/csrc/rrtmg_lw_host.h"
+#include "../../climt_amd/csrc/rrtmg_sw_device.h"
+#include "../../include/rrtmg_hip.h"
+
+using namespace rrtmg;
+
+namespace rrtmg {
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
+}
+
+template <int BAND>
+static void emu_lw_solve(const LwDev &d, const LwTab &T) {
+  const int ng = T.b[BAND - 1].ng;
+  std::vector<double> scr((size_t)LF_N * d.nlay);
+  for (int ig = 0; ig < ng; ++ig)
+    for (int col = 0; col < d.ncol; ++col) lw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1);
+}
+
+extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, double cpdair, const double *consts, char *errbuf, int errlen) {
+  auto fail = [&](int code, const std::string &m) { if (errbuf) { strncpy(errbuf, m.c_str(), errlen - 1); errbuf[errlen - 1] = 0; } return code; };
+  Blob blob;
+  std::string err;
+  if (!blob.load(blob_path, err)) return fail(3, err);
+  TableSet ts;
+  Constants k{};
+  k.pi = consts[0]; k.grav = consts[1]; k.planck = consts[2]; k.boltz = consts[3]; k.clight = consts[4];
+  k.avogad = consts[5]; k.alosmt = consts[6]; k.gascon = consts[7]; k.sbcnst = consts[8]; k.secdy = consts[9];
+  if (!build_tables(blob, "lw", cpdair, k.grav, k.secdy, ts, err)) return fail(3, err);
+  LwTab T{};
+  if (!build_lw_tab(ts, T, err)) return fail(3, err);
+  T.t = ts.flat.data();
+  const int N = a->ncol, L = a->nlay;
+  const size_t nl = (size_t)N * L, nl1 = (size_t)N * (L + 1);
+  LwDev d{};
+  d.ncol = N; d.nlay = L; d.icld = a->icld;
+  if (d.icld < 0 || d.icld > 3) d.icld = 2;
+  d.idrv = a->idrv ? 1 : 0;
+  d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
+  d.k = k;
+  d.fluxfac = (2.0 * asin(1.0)) * 2.e4;
+  if (!d.mcica && d.icld >= 2) return fail(20, "rtrnmr not built");
+  d.play = a->play; d.plev = a->plev; d.tlay = a->tlay; d.tlev = a->tlev; d.tsfc = a->tsfc; d.h2o = a->h2ovmr; d.o3 = a->o3vmr;
+  d.co2 = a->co2vmr; d.ch4 = a->ch4vmr; d.n2o = a->n2ovmr; d.o2 = a->o2vmr; d.cfc11 = a->cfc11vmr; d.cfc12 = a->cfc12vmr;
+  d.cfc22 = a->cfc22vmr; d.ccl4 = a->ccl4vmr; d.emis = a->emis; d.tauaer = a->tauaer;
+  const bool clouds = d.icld >= 1;
+  if (clouds) { d.cldfr = a->cldfr; d.taucld = a->taucld; d.cicewp = a->cicewp; d.cliqwp = a->cliqwp; d.reice = a->reice; d.reliq = a->reliq; }
+  std::vector<std::vector<double>> keep;
+  auto wd = [&](size_t n) { keep.emplace_back(n, 0.0); return keep.back().data(); };
+  d.fac00 = wd(nl); d.fac01 = wd(nl); d.fac10 = wd(nl); d.fac11 = wd(nl); d.selffac = wd(nl); d.selffrac = wd(nl); d.forfac = wd(nl);
+  d.forfrac = wd(nl); d.minorfrac = wd(nl); d.scaleminor = wd(nl); d.scaleminorn2 = wd(nl); d.colh2o = wd(nl); d.colco2 = wd(nl);
+  d.colo3 = wd(nl); d.coln2o = wd(nl); d.colco = wd(nl); d.colch4 = wd(nl); d.colo2 = wd(nl); d.colbrd = wd(nl); d.coldry = wd(nl);
+  d.wx1 = wd(nl); d.wx2 = wd(nl); d.wx3 = wd(nl); d.wx4 = wd(nl); d.secdiff = wd((size_t)N * 16);
+  std::vector<int32_t> idx(nl), laytrop(N), ncb(N, 1);
+  d.idx = idx.data(); d.laytrop = laytrop.data(); d.ncbands = ncb.data();
+  if (clouds) d.ctau = wd(nl * 16);
+  d.nw = (L + 63) / 64;
+  std::vector<uint64_t> mask, anym;
+  const int nk = d.idrv ? 6 : 4;
+  d.part = wd((size_t)kLwNGpt * nk * nl1);
+  d.uflx = a->uflx; d.dflx = a->dflx; d.hr = a->hr; d.uflxc = a->uflxc; d.dflxc = a->dflxc; d.hrc = a->hrc;
+  d.duflx_dt = a->duflx_dt; d.duflxc_dt = a->duflxc_dt;
+  int errflag = 0;
+  d.err = &errflag;
+  for (int c = 0; c < N; ++c) lw_prep_column(d, T, c);
+  if (clouds) {
+    if (!d.mcica) {
+      for (int c = 0; c < N; ++c) lw_cloud_column(d, T, c);
+    } else {
+      for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_cloudmc_layer(d, T, c, l);
+      mask.assign((size_t)kLwNGpt * d.nw * N, 0);
+      anym.assign((size_t)d.nw * N, 0);
+      d.mask = mask.data(); d.anymask = anym.data();
+      if (a->cldfmcl) {
+        for (int g = 0; g < kLwNGpt; ++g) for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c)
+          if (a->cldfmcl[((size_t)l * N + c) * kLwNGpt + g] > 1.e-12) mask[((size_t)g * d.nw + (l >> 6)) * N + c] |= 1ull << (l & 63);
+      } else if (a->irng == 0) {
+        for (int c = 0; c < N; ++c) kiss_mask_column(N, L, kLwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err, c);
+      } else {
+        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, a->cldfr, mask, d.nw);
+        d.mask = mask.data();
+      }
+      for (int c = 0; c < N; ++c) lw_anymask_column(d, c);
+    }
+  }
+  emu_lw_solve<1>(d, T); emu_lw_solve<2>(d, T); emu_lw_solve<3>(d, T); emu_lw_solve<4>(d, T); emu_lw_solve<5>(d, T); emu_lw_solve<6>(d, T);
+  emu_lw_solve<7>(d, T); emu_lw_solve<8>(d, T); emu_lw_solve<9>(d, T); emu_lw_solve<10>(d, T); emu_lw_solve<11>(d, T); emu_lw_solve<12>(d, T);
+  emu_lw_solve<13>(d, T); emu_lw_solve<14>(d, T); emu_lw_solve<15>(d, T); emu_lw_solve<16>(d, T);
+  for (int c = 0; c < N; ++c) lw_finish_column(d, T, c);
+  if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
+  return 0;
+}
+
+// stage check: taug / fracs of every (layer, g-point) of ONE column through lw_prep_column + lw_taug<>
+template <int BAND>
+static void emu_taug_band(const LwDev &d, const LwTab &T, double *taug, double *fracs) {
+  const int L = d.nlay;
+  for (int ig = 0; ig < T.b[BAND - 1].ng; ++ig)
+    for (int l = 0; l < L; ++l) {
+      LwLayerIn s;
+      lw_load_layer(d, (long)l * d.ncol, s);
+      double fr;
+      const double tg = lw_taug<BAND>(T, s, (l + 1) <= d.laytrop[0], ig, fr);
+      taug[(size_t)(T.b[BAND - 1].gs + ig) * L + l] = tg;    // Fortran (nlay, ngpt) order
+      fracs[(size_t)(T.b[BAND - 1].gs + ig) * L + l] = fr;
+    }
+}
+
+extern "C" int emu_lw_taumol(const rrtmg_lw_args *a, const char *blob_path, double cpdair, const double *consts, double *taug, double *fracs) {
+  Blob blob;
+  std::string err;
+  if (!blob.load(blob_path, err)) return 3;
+  TableSet ts;
+  Constants k{};
+  k.pi = consts[0]; k.grav = consts[1]; k.avogad = consts[5]; k.secdy = consts[9];
+  if (!build_tables(blob, "lw", cpdair, k.grav, k.secdy, ts, err)) return 3;
+  LwTab T{};
+  if (!build_lw_tab(ts, T, err)) return 3;
+  T.t = ts.flat.data();
+  const int L = a->nlay;
+  LwDev d{};
+  d.ncol = 1; d.nlay = L; d.k = k;
+  d.play = a->play; d.plev = a->plev; d.tlay = a->tlay; d.tlev = a->tlev; d.tsfc = a->tsfc; d.h2o = a->h2ovmr; d.o3 = a->o3vmr;
+  d.co2 = a->co2vmr; d.ch4 = a->ch4vmr; d.n2o = a->n2ovmr; d.o2 = a->o2vmr; d.cfc11 = a->cfc11vmr; d.cfc12 = a->cfc12vmr;
+  d.cfc22 = a->cfc22vmr; d.ccl4 = a->ccl4vmr; d.emis = a->emis;
+  std::vector<std::vector<double>> keep;
+  auto wd = [&](size_t n) { keep.emplace_back(n, 0.0); return keep.back().data(); };
+  d.fac00 = wd(L); d.fac01 = wd(L); d.fac10 = wd(L); d.fac11 = wd(L); d.selffac = wd(L); d.selffrac = wd(L); d.forfac = wd(L);
+  d.forfrac = wd(L); d.minorfrac = wd(L); d.scaleminor = wd(L); d.scaleminorn2 = wd(L); d.colh2o = wd(L); d.colco2 = wd(L);
+  d.colo3 = wd(L); d.coln2o = wd(L); d.colco = wd(L); d.colch4 = wd(L); d.colo2 = wd(L); d.colbrd = wd(L); d.coldry = wd(L);
+  d.wx1 = wd(L); d.wx2 = wd(L); d.wx3 = wd(L); d.wx4 = wd(L); d.secdiff = wd(16);
+  std::vector<int32_t> idx(L), laytrop(1);
+  d.idx = idx.data(); d.laytrop = laytrop.data();
+  int errflag = 0;
+  d.err = &errflag;
+  lw_prep_column(d, T, 0);
+  emu_taug_band<1>(d, T, taug, fracs); emu_taug_band<2>(d, T, taug, fracs); emu_taug_band<3>(d, T, taug, fracs); emu_taug_band<4>(d, T, taug, fracs);
+  emu_taug_band<5>(d, T, taug, fracs); emu_taug_band<6>(d, T, taug, fracs); emu_taug_band<7>(d, T, taug, fracs); emu_taug_band<8>(d, T, taug, fracs);
+  emu_taug_band<9>(d, T, taug, fracs); emu_taug_band<10>(d, T, taug, fracs); emu_taug_band<11>(d, T, taug, fracs); emu_taug_band<12>(d, T, taug, fracs);
+  emu_taug_band<13>(d, T, taug, fracs); emu_taug_band<14>(d, T, taug, fracs); emu_taug_band<15>(d, T, taug, fracs); emu_taug_band<16>(d, T, taug, fracs);
+  return laytrop[0];
+}
+
+// reduced table read-back for the reduction tests: builds tables on the host only
+extern "C" long emu_get_table(const char *which, const char *blob_path, double cpdair, const char *name, double *out, long cap) {
+  Blob blob;
+  std::string err;
+  if (!blob.load(blob_path, err)) return -3;
+  TableSet ts;
+  if (!build_tables(blob, which, cpdair, 9.80665, 86400.0, ts, err)) return -3;
+  auto it = ts.reg.find(name);
+  if (it == ts.reg.end()) return -1;
+  if (out) { if (cap < it->second.n) return -2; memcpy(out, ts.flat.data() + it->second.off, (size_t)it->second.n * 8); }
+  return it->second.n;
+}
