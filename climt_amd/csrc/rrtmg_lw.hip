@@ -6,7 +6,8 @@
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
 //   lw_solve_kernel<B>   16 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
-//   lw_finish_kernel     <<<ncol/64>>>
+//   lw_flux_kernel       <<<ncol/64, nlay+1>>>  band / g-point integration per interface
+//   lw_heat_kernel       <<<ncol/64, nlay>>>    heating rates
 #include "rrtmg_ctx.h"
 #include "rrtmg_lw_device.h"
 #include "rrtmg_lw_host.h"
@@ -39,9 +40,13 @@ __global__ void __launch_bounds__(64) lw_solve_kernel(LwDev d, LwTab T) {
   double *scr = d.scratch + (long)blockIdx.x * LF_N * d.nlay * 64 + threadIdx.x;
   lw_solve_thread<BAND>(d, T, col, ig, scr, 64);
 }
-__global__ void __launch_bounds__(64) lw_finish_kernel(LwDev d, LwTab T) {
+__global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_finish_column(d, T, col);
+  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y);
+}
+__global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_heat_layer(d, T, col, blockIdx.y);
 }
 
 template <int BAND>
@@ -193,7 +198,8 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   launch_lw_solve<5>(d, T, s); launch_lw_solve<6>(d, T, s); launch_lw_solve<7>(d, T, s); launch_lw_solve<8>(d, T, s);
   launch_lw_solve<9>(d, T, s); launch_lw_solve<10>(d, T, s); launch_lw_solve<11>(d, T, s); launch_lw_solve<12>(d, T, s);
   launch_lw_solve<13>(d, T, s); launch_lw_solve<14>(d, T, s); launch_lw_solve<15>(d, T, s); launch_lw_solve<16>(d, T, s);
-  hipLaunchKernelGGL(lw_finish_kernel, gcol, blk, 0, s, d, T);
+  hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
+  hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
   int herr = 0;

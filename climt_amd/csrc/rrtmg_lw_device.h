@@ -8,7 +8,7 @@
 //   lw_solve_thread  one thread per (column, g-point): downward sweep (taumol for the layer, Planck
 //                    terms, no-scattering recurrence; layer state spilled to a [field][layer][lane]
 //                    scratch slab), surface reflection, upward sweep.
-//   lw_finish_column band / g-point integration, flux scaling, heating rates.
+//   lw_flux_level / lw_heat_layer  band / g-point integration, flux scaling; heating rates.
 //
 // Reference followed (climt/_lib/rrtmg_lw/): rrtmg_lw_rad.nomcica.f90:80-569,:572-900 (driver, inatm),
 // rrtmg_lw_rad.f90, rrtmg_lw_setcoef.f90:31-415, rrtmg_lw_taumol.f90:31-3147 (taugb1..16),
@@ -905,36 +905,42 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
 }
 
 // band / g-point integration and heating rates (rrtmg_lw_rtrn.f90:528-585)
-RRTMG_HD void lw_finish_column(const LwDev &d, const LwTab &T, int col) {
+// one thread per (column, interface level)
+RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev) {
   const int L = d.nlay, N = d.ncol;
   const int nk = d.idrv ? 6 : 4;
   const double wtdiff = 0.5;
   const double *delwave = T.t + T.delwave;
-  double fnet_p = 0.0, fnetc_p = 0.0, pz_p = 0.0;
-  for (int lev = 0; lev <= L; ++lev) {
-    double tot[6] = {0, 0, 0, 0, 0, 0};
-    for (int b = 0; b < kLwNBand; ++b) {
-      double acc[6] = {0, 0, 0, 0, 0, 0};
-      for (int g = 0; g < T.b[b].ng; ++g) {
-        const int iw = T.b[b].gs + g;
-        for (int k = 0; k < nk; ++k) acc[k] = acc[k] + d.part[(((long)iw * nk + k) * (L + 1) + lev) * N + col];
-      }
-      for (int k = 0; k < 4; ++k) tot[k] = tot[k] + (acc[k] * wtdiff) * delwave[b];
-      if (d.idrv) for (int k = 4; k < 6; ++k) tot[k] = tot[k] + (acc[k] * wtdiff) * delwave[b] * d.fluxfac;
+  const long st = (long)(L + 1) * N;
+  double tot[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = 0; b < kLwNBand; ++b) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
+    const int g0 = T.b[b].gs, g1 = g0 + T.b[b].ng;
+    for (int iw = g0; iw < g1; ++iw) {
+      const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * N + col;
+      a0 = a0 + p[0]; a1 = a1 + p[st]; a2 = a2 + p[2 * st]; a3 = a3 + p[3 * st];
+      if (d.idrv) { a4 = a4 + p[4 * st]; a5 = a5 + p[5 * st]; }
     }
-    const long o = (long)lev * N + col;
-    const double uf = tot[0] * d.fluxfac, df = tot[1] * d.fluxfac, ucf = tot[2] * d.fluxfac, dcf = tot[3] * d.fluxfac;
-    d.uflx[o] = uf; d.dflx[o] = df; d.uflxc[o] = ucf; d.dflxc[o] = dcf;
-    if (d.idrv) { d.duflx_dt[o] = tot[4]; d.duflxc_dt[o] = tot[5]; }
-    const double fnet = uf - df, fnetc = ucf - dcf;
-    const double pz = d.plev[o];
-    if (lev > 0) {
-      const long ol = (long)(lev - 1) * N + col;
-      d.hr[ol] = T.heatfac * (fnet_p - fnet) / (pz_p - pz);
-      d.hrc[ol] = T.heatfac * (fnetc_p - fnetc) / (pz_p - pz);
+    tot[0] = tot[0] + (a0 * wtdiff) * delwave[b]; tot[1] = tot[1] + (a1 * wtdiff) * delwave[b];
+    tot[2] = tot[2] + (a2 * wtdiff) * delwave[b]; tot[3] = tot[3] + (a3 * wtdiff) * delwave[b];
+    if (d.idrv) {
+      tot[4] = tot[4] + (a4 * wtdiff) * delwave[b] * d.fluxfac;
+      tot[5] = tot[5] + (a5 * wtdiff) * delwave[b] * d.fluxfac;
     }
-    fnet_p = fnet; fnetc_p = fnetc; pz_p = pz;
   }
+  const long o = (long)lev * N + col;
+  d.uflx[o] = tot[0] * d.fluxfac; d.dflx[o] = tot[1] * d.fluxfac; d.uflxc[o] = tot[2] * d.fluxfac; d.dflxc[o] = tot[3] * d.fluxfac;
+  if (d.idrv) { d.duflx_dt[o] = tot[4]; d.duflxc_dt[o] = tot[5]; }
+}
+// one thread per (column, layer)
+RRTMG_HD void lw_heat_layer(const LwDev &d, const LwTab &T, int col, int lay) {
+  const int N = d.ncol;
+  const long o0 = (long)lay * N + col, o1 = o0 + N;
+  const double fnet0 = d.uflx[o0] - d.dflx[o0], fnet1 = d.uflx[o1] - d.dflx[o1];
+  const double fnetc0 = d.uflxc[o0] - d.dflxc[o0], fnetc1 = d.uflxc[o1] - d.dflxc[o1];
+  const double dp = d.plev[o0] - d.plev[o1];
+  d.hr[o0] = T.heatfac * (fnet0 - fnet1) / dp;
+  d.hrc[o0] = T.heatfac * (fnetc0 - fnetc1) / dp;
 }
 
 }  // namespace rrtmg

@@ -6,7 +6,8 @@
 //   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
 //   sw_kiss_kernel / mask upload (mcica)         sub-column cloud mask
 //   sw_solve_kernel<B>  14 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
-//   sw_finish_kernel    <<<ncol/64>>>            g-point sum, heating rates
+//   sw_flux_kernel      <<<ncol/64, nlay+1>>>    g-point sum per interface
+//   sw_heat_kernel      <<<ncol/64, nlay>>>      heating rates
 #include "rrtmg_ctx.h"
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
@@ -62,9 +63,13 @@ __global__ void __launch_bounds__(64) sw_solve_kernel(SwDev d, SwTab T) {
   sw_solve_thread<BAND>(d, T, col, ig, scr, 64);
 }
 
-__global__ void __launch_bounds__(64) sw_finish_kernel(SwDev d, SwTab T) {
+__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_finish_column(d, T, col);
+  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y);
+}
+__global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) sw_heat_layer(d, T, col, blockIdx.y);
 }
 
 template <int BAND>
@@ -259,7 +264,8 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   launch_solve<20>(d, T, s); launch_solve<21>(d, T, s); launch_solve<22>(d, T, s); launch_solve<23>(d, T, s);
   launch_solve<24>(d, T, s); launch_solve<25>(d, T, s); launch_solve<26>(d, T, s); launch_solve<27>(d, T, s);
   launch_solve<28>(d, T, s); launch_solve<29>(d, T, s);
-  hipLaunchKernelGGL(sw_finish_kernel, gcol, blk, 0, s, d, T);
+  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d);
+  hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
   // ---- status + outputs -------------------------------------------------------------------

@@ -11,7 +11,7 @@
 //                    up (taumol + delta scaling + reftra + upward adding recurrence, level state
 //                    spilled to a [field][layer][lane] scratch slab) and down (downward adding
 //                    recurrence + flux assembly).
-//   sw_finish_column spectral integration in g-point order + heating rates.
+//   sw_flux_level / sw_heat_layer  spectral integration in g-point order; heating rates.
 //
 // Reference followed (climt/_lib/rrtmg_sw/): rrtmg_sw_rad.nomcica.f90:587-816 (driver),
 // :846-1539 (inatm_sw), rrtmg_sw_setcoef.f90:49-305, rrtmg_sw_taumol.f90:50-1790,
@@ -814,27 +814,27 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
 
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
-RRTMG_HD void sw_finish_column(const SwDev &d, const SwTab &T, int col) {
+// one thread per (column, interface level): g-point sum in reference order
+RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev) {
   const int L = d.nlay, N = d.ncol;
-  double netp = 0.0, netcp = 0.0;
-  for (int lev = 0; lev <= L; ++lev) {
-    double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
-    for (int iw = 0; iw < kSwNGpt; ++iw) {
-      const double *p = d.part + ((long)iw * 4 * (L + 1) + lev) * N + col;
-      const long st = (long)(L + 1) * N;
-      fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
-    }
-    const long o = (long)lev * N + col;
-    d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
-    const double net = fd - fu, netc = cd - cu;
-    if (lev > 0) {
-      const long ol = (long)(lev - 1) * N + col;
-      const double zdpgcp = T.heatfac / d.pdp[ol];
-      d.swhrc[ol] = (netc - netcp) * zdpgcp;
-      d.swhr[ol] = (net - netp) * zdpgcp;
-    }
-    netp = net; netcp = netc;
+  double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
+  const long st = (long)(L + 1) * N;
+  for (int iw = 0; iw < kSwNGpt; ++iw) {
+    const double *p = d.part + ((long)iw * 4 * (L + 1) + lev) * N + col;
+    fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
   }
+  const long o = (long)lev * N + col;
+  d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
+}
+// one thread per (column, layer): heating rates from the net-flux divergence
+RRTMG_HD void sw_heat_layer(const SwDev &d, const SwTab &T, int col, int lay) {
+  const int N = d.ncol;
+  const long o0 = (long)lay * N + col, o1 = o0 + N;
+  const double net0 = d.swdflx[o0] - d.swuflx[o0], net1 = d.swdflx[o1] - d.swuflx[o1];
+  const double netc0 = d.swdflxc[o0] - d.swuflxc[o0], netc1 = d.swdflxc[o1] - d.swuflxc[o1];
+  const double zdpgcp = T.heatfac / d.pdp[o0];
+  d.swhrc[o0] = (netc1 - netc0) * zdpgcp;
+  d.swhr[o0] = (net1 - net0) * zdpgcp;
 }
 
 }  // namespace rrtmg

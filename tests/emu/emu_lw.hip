@@ -92,7 +92,8 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   emu_lw_solve<1>(d, T); emu_lw_solve<2>(d, T); emu_lw_solve<3>(d, T); emu_lw_solve<4>(d, T); emu_lw_solve<5>(d, T); emu_lw_solve<6>(d, T);
   emu_lw_solve<7>(d, T); emu_lw_solve<8>(d, T); emu_lw_solve<9>(d, T); emu_lw_solve<10>(d, T); emu_lw_solve<11>(d, T); emu_lw_solve<12>(d, T);
   emu_lw_solve<13>(d, T); emu_lw_solve<14>(d, T); emu_lw_solve<15>(d, T); emu_lw_solve<16>(d, T);
-  for (int c = 0; c < N; ++c) lw_finish_column(d, T, c);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev);
+  for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
 }
