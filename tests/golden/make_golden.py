@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference checkout (run in the build container only).
+
+1. climt_cache_<Class>-<descriptor>.npz -- (input state, expected output) pairs recovered from the
+   reference's own golden caches tests/cached_component_output/TestRRTMG*-{column,3d}[_stepping]-{0,1}.cache
+   (netCDF3).  `*_stepping-1.cache` is the full stepped state: every input array,
+   with air_temperature advanced by 10 s x tendency (Euler first step of AdamsBashforth), so the
+   un-stepped temperature is recovered as T1 - 10 s * tendency / 86400.
+2. ref_sw_*.npz / ref_lw_*.npz -- outputs of the reference Fortran (oracle/_ref) on seeded synthetic
+   columns (climt_amd.synthetic) for the boundary-level parity tests that must run where the
+   reference library is not available.  LW fixtures are on the SYNTHETIC k-tables of the LW blob.
+"""
+import os
+import sys
+
+import numpy as np
+from scipy.io import netcdf_file
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+REF = os.environ.get("CLIMT_REFERENCE", "/root/reference")
+CACHE = os.path.join(REF, "tests", "cached_component_output")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def read_cache(fn):
+    f = netcdf_file(os.path.join(CACHE, fn), mmap=False)
+    out = {}
+    for k, v in f.variables.items():
+        units = getattr(v, "units", b"")
+        units = units.decode("utf-8") if isinstance(units, bytes) else units
+        out[k] = (np.array(v[...]), tuple(v.dimensions), units)
+    return out
+
+
+def cache_case(cls, desc):
+    tend = read_cache("%s-%s-0.cache" % (cls, desc))
+    diag = read_cache("%s-%s-1.cache" % (cls, desc))
+    step = "%s-%s_stepping-1.cache" % (cls, desc)
+    if not os.path.exists(os.path.join(CACHE, step)):
+        return None
+    state = read_cache(step)
+    t1, dims, units = state["air_temperature"]
+    dt = 10.0
+    tt = tend["air_temperature"][0]
+    # bring the tendency to the state's dim order
+    tdims = tend["air_temperature"][1]
+    tt = np.transpose(tt, [tdims.index(d) for d in dims])
+    state["air_temperature"] = (t1 - dt * tt / 86400.0, dims, units)
+    save = {}
+    for k, (v, d, u) in state.items():
+        if k == "time":
+            continue
+        save["state/%s/values" % k] = v
+        save["state/%s/dims" % k] = np.array(",".join(d))
+        save["state/%s/units" % k] = np.array(u)
+    for grp, dd in (("tend", tend), ("diag", diag)):
+        for k, (v, d, u) in dd.items():
+            save["%s/%s/values" % (grp, k)] = v
+            save["%s/%s/dims" % (grp, k)] = np.array(",".join(d))
+            save["%s/%s/units" % (grp, k)] = np.array(u)
+    np.savez_compressed(os.path.join(OUT, "climt_cache_%s-%s.npz" % (cls, desc)), **save)
+    return len(save)
+
+
+def reference_cases():
+    from climt_amd.synthetic import make_columns, overcast
+    from oracle.ref_driver import RefLW, RefSW
+    from tools.pack_tables import read_blob
+    from tools.synth_lw_tables import fill_reference_from_blob
+    sw = RefSW()
+    blob = read_blob(os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin"))
+    lw = RefLW()
+    lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+    base = dict(icld=1, iaer=0, adjes=1.0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1)
+    cases = {}
+    cases["clear_L60"] = (dict(ncol=48, nlay=60, cloudy=False, seed=11), {}, False)
+    cases["clear_L30"] = (dict(ncol=32, nlay=30, cloudy=False, seed=12), {}, False)
+    cases["overcast_L60"] = (dict(ncol=48, nlay=60, cloudy=True, seed=13), {"_overcast": True}, False)
+    cases["mcica_kiss_random"] = (dict(ncol=48, nlay=60, cloudy=True, seed=14), dict(icld=1, irng=0, permuteseed=684), True)
+    cases["mcica_kiss_maxrand"] = (dict(ncol=48, nlay=60, cloudy=True, seed=15), dict(icld=2, irng=0, permuteseed=112), True)
+    cases["mcica_mt_max"] = (dict(ncol=24, nlay=40, cloudy=True, seed=16), dict(icld=3, irng=1, permuteseed=209652396), True)
+    for name, (gen, extra, mcica) in cases.items():
+        c = make_columns(**gen)
+        if extra.pop("_overcast", False):
+            c = overcast(c)
+        c.update(base)
+        c.update(extra)
+        save = {"gen/" + k: np.array(v) for k, v in gen.items()}
+        save.update({"flag/" + k: np.array(v) for k, v in c.items() if not isinstance(v, np.ndarray)})
+        save["flag/_mcica"] = np.array(int(mcica))
+        save["flag/_overcast"] = np.array(int(name.startswith("overcast")))
+        r = sw.fluxes(c, mcica=mcica)
+        for k in ("swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc"):
+            save["sw/" + k] = r[k]
+        # non-McICA LW: random overlap only (rtrn); McICA LW handles all overlaps
+        cl = dict(c)
+        if not mcica:
+            cl["icld"] = 1
+        r = lw.fluxes(cl, mcica=mcica)
+        for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc"):
+            save["lw/" + k] = r[k]
+        np.savez_compressed(os.path.join(OUT, "ref_%s.npz" % name), **save)
+        print("reference case", name)
+
+
+if __name__ == "__main__":
+    n = 0
+    for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
+                "TestRRTMGLongwaveWithExternalInterfaceTemperature", "TestRRTMGShortwave", "TestRRTMGShortwaveMCICA"):
+        for desc in ("column", "3d"):
+            r = cache_case(cls, desc)
+            print(cls, desc, "->", r)
+    reference_cases()

@@ -1,0 +1,172 @@
+"""Shared test helpers: golden-fixture loaders, the host emulator of the device functions (CPU tests),
+and state builders.  TEST INFRASTRUCTURE ONLY."""
+import ctypes as C
+import datetime
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from climt_amd._lib import LwArgs, SwArgs, LW_OUT, SW_OUT, SW_DATA, LW_DATA, _LW_FIELDS, _LW_FLAGS, _SW_FIELDS, _SW_FLAGS  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_SO = os.path.join(ROOT, "tests", "_emu", "librrtmg_emu.so")
+
+CONSTANTS = dict(pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852e-16, clight=2.99792458e10,
+                 avogad=6.022140857e23, alosmt=2.6867774e19, gascon=8.3144598e7, sbcnst=5.670367e-12, secdy=86400.0)
+CPDAIR = 1004.64
+_CONST_VEC = np.array([CONSTANTS[n] for n in "pi grav planck boltz clight avogad alosmt gascon sbcnst secdy".split()])
+
+_emu = None
+
+
+def emu_lib():
+    """Host emulation of the device functions (tests/emu); built on demand with hipcc (no GPU needed)."""
+    global _emu
+    if _emu is None:
+        srcs = [os.path.join(ROOT, "tests", "emu", f) for f in ("emu_sw.hip", "emu_lw.hip")]
+        srcs += [os.path.join(ROOT, "climt_amd", "csrc", f) for f in os.listdir(os.path.join(ROOT, "climt_amd", "csrc"))]
+        if not os.path.exists(EMU_SO) or os.path.getmtime(EMU_SO) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call([os.path.join(ROOT, "tests", "emu", "build.sh")])
+        _emu = C.CDLL(EMU_SO)
+        _emu.emu_get_table.restype = C.c_long
+        _emu.emu_get_table.argtypes = [C.c_char_p, C.c_char_p, C.c_double, C.c_char_p, C.c_void_p, C.c_long]
+    return _emu
+
+
+def _fill(a, inp, fields, flags, keep):
+    for k, f in flags.items():
+        if k in inp:
+            setattr(a, f, int(inp[k]))
+    for k, f in fields.items():
+        v = inp.get(k)
+        if v is None:
+            continue
+        arr = np.ascontiguousarray(v, dtype=np.float64)
+        keep.append(arr)
+        setattr(a, f, arr.ctypes.data)
+
+
+class EmuContext:
+    """Drop-in for climt_amd._lib.Context that runs the device functions on the host (tests only)."""
+
+    def __init__(self, device=0):
+        self.lib = emu_lib()
+        self.device = device
+
+    def set_constants(self, **k):
+        pass
+
+    def sw_init(self, cpdair, blob=None):
+        self.cpd_sw = cpdair
+
+    def lw_init(self, cpdair, blob=None):
+        self.cpd_lw = cpdair
+
+    def lw_tables_synthetic(self):
+        return True
+
+    def close(self):
+        pass
+
+    def sw_fluxes(self, inp, mcica=False, out=None, memspace=0):
+        nlay, ncol = inp["play"].shape
+        a, keep = SwArgs(), []
+        a.ncol, a.nlay, a.memspace, a.mcica = ncol, nlay, 0, int(bool(mcica))
+        a.icld, a.inflgsw, a.iceflgsw, a.liqflgsw, a.dyofyr = 1, 2, 1, 1, 1
+        a.adjes, a.scon, a.solcycfrac = float(inp.get("adjes", 1.0)), float(inp.get("scon", 1367.0)), float(inp.get("solcycfrac", 0.0))
+        _fill(a, inp, _SW_FIELDS, _SW_FLAGS, keep)
+        if out is None:
+            out = {k: np.zeros((nlay + lev, ncol)) for k, lev in SW_OUT}
+        for k, _ in SW_OUT:
+            setattr(a, k, out[k].ctypes.data)
+        eb = C.create_string_buffer(512)
+        rc = self.lib.emu_sw_fluxes(C.byref(a), SW_DATA.encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
+        if rc:
+            from climt_amd._lib import RRTMGError
+            raise RRTMGError(rc, eb.value.decode())
+        return out
+
+    def lw_fluxes(self, inp, mcica=False, out=None, memspace=0):
+        nlay, ncol = inp["play"].shape
+        a, keep = LwArgs(), []
+        a.ncol, a.nlay, a.memspace, a.mcica = ncol, nlay, 0, int(bool(mcica))
+        a.icld, a.inflglw, a.iceflglw, a.liqflglw = 1, 2, 1, 1
+        _fill(a, inp, _LW_FIELDS, _LW_FLAGS, keep)
+        if out is None:
+            out = {k: np.zeros((nlay + lev, ncol)) for k, lev in LW_OUT}
+            if a.idrv:
+                out["duflx_dt"] = np.zeros((nlay + 1, ncol))
+                out["duflxc_dt"] = np.zeros((nlay + 1, ncol))
+        for k in out:
+            setattr(a, k, out[k].ctypes.data)
+        eb = C.create_string_buffer(512)
+        rc = self.lib.emu_lw_fluxes(C.byref(a), LW_DATA.encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
+        if rc:
+            from climt_amd._lib import RRTMGError
+            raise RRTMGError(rc, eb.value.decode())
+        return out
+
+    def mcica_mask(self, which, play, cldfrac, icld, permuteseed, irng):
+        nlay, ncol = play.shape
+        nsub = 112 if which == "sw" else 140
+        out = np.zeros((nlay, ncol, nsub))
+        p, c = np.ascontiguousarray(play, dtype=np.float64), np.ascontiguousarray(cldfrac, dtype=np.float64)
+        self.lib.emu_mask(0 if which == "sw" else 1, ncol, nlay, int(icld), int(permuteseed), int(irng),
+                          p.ctypes.data_as(C.c_void_p), c.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def get_table(self, name):
+        which = name.split("/")[0]
+        blob = (SW_DATA if which == "sw" else LW_DATA).encode()
+        n = self.lib.emu_get_table(which.encode(), blob, CPDAIR, name.encode(), None, 0)
+        if n < 0:
+            raise KeyError(name)
+        out = np.empty(n)
+        self.lib.emu_get_table(which.encode(), blob, CPDAIR, name.encode(), out.ctypes.data, n)
+        return out
+
+
+# ---- golden fixtures -------------------------------------------------------------------------
+REF_CASES = ("clear_L60", "clear_L30", "overcast_L60", "mcica_kiss_random", "mcica_kiss_maxrand", "mcica_mt_max")
+
+
+def load_ref_case(name):
+    """-> (inputs dict at the C-ABI boundary, mcica flag, expected {'sw': {...}, 'lw': {...}})."""
+    from climt_amd.synthetic import make_columns, overcast
+    z = np.load(os.path.join(GOLDEN, "ref_%s.npz" % name))
+    gen = {k[4:]: z[k].item() for k in z.files if k.startswith("gen/")}
+    gen["cloudy"] = bool(gen["cloudy"])
+    c = make_columns(**gen)
+    flags = {k[5:]: z[k].item() for k in z.files if k.startswith("flag/")}
+    if flags.pop("_overcast"):
+        c = overcast(c)
+    mcica = bool(flags.pop("_mcica"))
+    c.update(flags)
+    exp = {"sw": {k[3:]: z[k] for k in z.files if k.startswith("sw/")}, "lw": {k[3:]: z[k] for k in z.files if k.startswith("lw/")}}
+    return c, mcica, exp
+
+
+def load_cache_case(cls, desc):
+    """Reference golden cache -> (state of DataArrays, expected tendencies, expected diagnostics)."""
+    from climt_amd._sympl_compat import DataArray
+    z = np.load(os.path.join(GOLDEN, "climt_cache_%s-%s.npz" % (cls, desc)))
+    groups = {"state": {}, "tend": {}, "diag": {}}
+    for k in z.files:
+        grp, name, what = k.split("/")
+        groups[grp].setdefault(name, {})[what] = z[k]
+    def mk(d):
+        dims = str(d["dims"])
+        return DataArray(d["values"], dims=tuple(x for x in dims.split(",") if x), attrs={"units": str(d["units"])})
+    state = {n: mk(d) for n, d in groups["state"].items()}
+    state["time"] = datetime.datetime(2000, 1, 1)
+    return state, {n: mk(d) for n, d in groups["tend"].items()}, {n: mk(d) for n, d in groups["diag"].items()}
+
+
+def maxdiff(a, b):
+    return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))

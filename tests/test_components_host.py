@@ -1,0 +1,151 @@
+"""CPU tests of the Python host layer (component classes, sympl stand-in, helpers).  The library context is
+replaced by the host emulator of the device functions (tests/helpers.EmuContext) -- test infrastructure only."""
+import inspect
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+import climt_amd
+from climt_amd import _sympl_compat as sc
+from climt_amd._util import get_interface_values, mass_to_volume_mixing_ratio
+from climt_amd.rrtmg import common, longwave, shortwave
+from helpers import GOLDEN, EmuContext, load_cache_case, maxdiff
+
+
+@pytest.fixture(autouse=True)
+def emulated_context(monkeypatch):
+    def mk(device):
+        return EmuContext(device)
+    monkeypatch.setattr(shortwave, "make_context", mk)
+    monkeypatch.setattr(longwave, "make_context", mk)
+
+
+REF_IF = json.load(open(os.path.join(GOLDEN, "reference_interface.json")))
+
+
+@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave])
+def test_interface_identical_to_reference(cls):
+    """class attributes, the three property dicts and constructor defaults equal the reference's."""
+    ref = REF_IF[cls.__name__]
+    for name, val in ref.items():
+        if name == "__init__":
+            sig = inspect.signature(cls.__init__)
+            for k, v in val.items():
+                assert sig.parameters[k].default == v, (k, sig.parameters[k].default, v)
+            continue
+        assert getattr(cls, name) == val, name
+    for k, v in REF_IF["options"].items():
+        assert getattr(common, k) == v
+
+
+def _check_against_cache(comp, cls, desc, tol):
+    state, tend, diag = load_cache_case(cls, desc)
+    np.random.seed(0)       # tests/test_components.py:148
+    t, d = comp(state)
+    assert set(t) == set(tend) and set(d) == set(diag)
+    for got, exp in ((t, tend), (d, diag)):
+        for k in exp:
+            assert got[k].attrs["units"].replace("degK", "K") == exp[k].attrs["units"].replace("degK", "K")
+            assert set(got[k].dims) == set(exp[k].dims)
+            g = np.transpose(got[k].values, [got[k].dims.index(x) for x in exp[k].dims])
+            assert not np.isnan(g).any()
+            if tol is not None:
+                assert maxdiff(g, exp[k].values) <= tol, (k, maxdiff(g, exp[k].values))
+    return t, d
+
+
+def test_shortwave_reproduces_reference_cache_column():
+    """The reference's own regression criterion |d| <= 1e-8 (tests/test_components.py:355-356)."""
+    _check_against_cache(climt_amd.RRTMGShortwave(), "TestRRTMGShortwave", "column", 1e-8)
+
+
+def test_shortwave_mcica_reproduces_reference_cache():
+    # TestRRTMGShortwaveMCICA: default Mersenne twister, seed drawn after np.random.seed(0) = 209652396
+    _check_against_cache(climt_amd.RRTMGShortwave(mcica=True), "TestRRTMGShortwaveMCICA", "3d", 1e-8)
+    _check_against_cache(climt_amd.RRTMGShortwave(mcica=True), "TestRRTMGShortwaveMCICA", "column", 1e-8)
+
+
+@pytest.mark.parametrize("cls,desc,kw", [
+    ("TestRRTMGLongwave", "column", {}),
+    ("TestRRTMGLongwaveWithClouds", "column", dict(cloud_optical_properties="single_cloud_type")),
+    ("TestRRTMGLongwaveWithExternalInterfaceTemperature", "column", dict(calculate_interface_temperature=False)),
+    ("TestRRTMGLongwaveMCICA", "3d", dict(mcica=True)),
+])
+def test_longwave_structure_on_reference_states(cls, desc, kw):
+    """LW numbers cannot be compared with the caches (synthetic k-tables: LW parity is pinned against the
+    reference Fortran on the same tables instead); names, dims, units and finiteness are."""
+    t, d = _check_against_cache(climt_amd.RRTMGLongwave(**kw), cls, desc, None)
+    assert d["air_temperature_tendency_from_longwave"].values is not None
+    assert np.array_equal(d["air_temperature_tendency_from_longwave"].values, t["air_temperature"].values)
+
+
+def test_state_axis_permutation_invariance():
+    """tests/test_components.py:291-327: reversed / transposed horizontal axes give the same answer."""
+    state, _, _ = load_cache_case("TestRRTMGShortwaveMCICA", "3d")
+    comp = climt_amd.RRTMGShortwave()
+    for st in state.values():
+        if hasattr(st, "values") and "mid_levels" in st.dims:
+            pass
+    state["cloud_area_fraction_in_atmosphere_layer"].values[:] = 0.0
+    t0, d0 = comp(state)
+    tr = {}
+    for k, v in state.items():
+        if hasattr(v, "dims") and "lat" in v.dims and "lon" in v.dims:
+            order = list(range(v.values.ndim))
+            i, j = v.dims.index("lat"), v.dims.index("lon")
+            order[i], order[j] = order[j], order[i]
+            dims = list(v.dims); dims[i], dims[j] = dims[j], dims[i]
+            tr[k] = sc.DataArray(np.transpose(v.values, order), dims=dims, attrs=v.attrs)
+        else:
+            tr[k] = v
+    t1, d1 = comp(tr)
+    for k in d0:
+        a = d0[k]
+        b = d1[k]
+        bb = np.transpose(b.values, [b.dims.index(x) for x in a.dims])
+        assert np.array_equal(a.values, bb), k
+
+
+def test_mcica_log_messages(caplog):
+    """messages asserted by tests/test_components.py:454-461, :507-530"""
+    with caplog.at_level(logging.INFO):
+        climt_amd.RRTMGShortwave(mcica=True, cloud_overlap_method="clear_only")
+        assert "no clouds" in caplog.text.lower()
+        caplog.clear()
+        climt_amd.RRTMGShortwave(mcica=True, cloud_optical_properties="single_cloud_type")
+        assert "must be 'direct_input' or 'liquid_and_ice_clouds'" in caplog.text
+        caplog.clear()
+        climt_amd.RRTMGShortwave(mcica=True, cloud_ice_properties="ebert_curry_one")
+        assert "should not be set to 'ebert_curry_one'" in caplog.text
+        caplog.clear()
+        climt_amd.RRTMGShortwave(mcica=True, cloud_liquid_water_properties="radius_independent_absorption")
+        assert "must be set to 'radius_dependent_absorption'" in caplog.text
+        caplog.clear()
+        climt_amd.RRTMGLongwave(mcica=True, cloud_overlap_method="clear_only")
+        assert "no clouds" in caplog.text.lower()
+
+
+def test_host_helpers():
+    q = np.array([[0.01, 0.02]])
+    assert np.allclose(mass_to_volume_mixing_ratio(q, 18.02), q * 28.964 / 18.02)
+    with pytest.raises(ValueError):
+        mass_to_volume_mixing_ratio(q)
+    p = np.array([[900.0], [700.0], [400.0]]); pi = np.array([[1000.0], [800.0], [550.0], [250.0]])
+    t = np.array([[290.0], [270.0], [240.0]]); ts = np.array([300.0])
+    ti = get_interface_values(t, ts, p, pi)
+    assert ti.shape == (4, 1) and ti[0, 0] == 300.0 and ti[-1, 0] == 240.0
+    w = (np.log(800.0) - np.log(700.0)) / (np.log(900.0) - np.log(700.0))
+    assert np.isclose(ti[1, 0], 270.0 - w * (270.0 - 290.0))
+
+
+def test_unit_conversion_of_the_sympl_standin():
+    if sc.HAVE_SYMPL:
+        pytest.skip("real sympl present")
+    assert np.isclose(sc.convert_units(101320.0, "Pa", "mbar"), 1013.2)
+    assert np.isclose(sc.convert_units(0.3, "kg/m**2", "g m^-2"), 300.0)
+    assert sc.convert_units(5.0, "\xb5m", "micrometer") == 5.0
+    with pytest.raises(ValueError):
+        sc.convert_units(1.0, "Pa", "K")
