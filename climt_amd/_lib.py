@@ -68,6 +68,7 @@ def load_library():
     lib.rrtmg_hip_get_table.argtypes = [_vp, C.c_char_p, _vp, C.c_long]
     lib.rrtmg_hip_lw_tables_synthetic.argtypes = [_vp]
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
+    lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
     return lib
@@ -137,6 +138,12 @@ class Context:
     @property
     def stream(self):
         return self.lib.rrtmg_hip_stream(self.h)
+
+    def kernel_ms(self, which):
+        """HIP-event duration (ms) of the last sw_solve_all (which='sw') / lw_solve_all ('lw') launch."""
+        ms = C.c_double(0.0)
+        self._ck(self.lib.rrtmg_hip_kernel_ms(self.h, 0 if which == "sw" else 1, C.byref(ms)))
+        return ms.value
 
     def synchronize(self):
         self._ck(self.lib.rrtmg_hip_synchronize(self.h))

@@ -36,6 +36,8 @@ struct rrtmg_ctx {
   // grow-only device work buffers, by name
   std::map<std::string, rrtmg::DevBuf> bufs;
   int *err_dev = nullptr;
+  hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [sw|lw][start|stop] around the solve kernel
+  bool ev_valid[2] = {false, false};
 
   int fail(int code, const char *fmt, ...) {
     char tmp[1024];

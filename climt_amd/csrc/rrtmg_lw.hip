@@ -5,7 +5,7 @@
 //   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
-//   lw_solve_kernel<B>   16 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
+//   lw_solve_all_kernel  one launch: grid = tiles(64 columns) x 35 g-groups (XCD-aware), block = 4 wavefronts
 //   lw_flux_kernel       <<<ncol/64, nlay+1>>>  band / g-point integration per interface
 //   lw_heat_kernel       <<<ncol/64, nlay>>>    heating rates
 #include "rrtmg_ctx.h"
@@ -31,15 +31,41 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_anymask_column(d, col);
 }
-template <int BAND>
-__global__ void __launch_bounds__(64) lw_solve_kernel(LwDev d, LwTab T) {
-  const int ng = T.b[BAND - 1].ng;
-  const int tile = blockIdx.x / ng, ig = blockIdx.x - tile * ng;
+// All 140 g-points in ONE launch; same (tile, g-group) -> XCD mapping as the shortwave (rrtmg_sw.hip).
+constexpr int kLwGroup = 4;
+__global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8) {
+  const int q = blockIdx.x;
+  const int xcd = q & 7, r = q >> 3;
+  const int ngrp = kLwNGpt / kLwGroup;
+  const int grp = r % ngrp, tile = (r / ngrp) * 8 + xcd;
+  (void)ntile8;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + (long)blockIdx.x * LF_N * d.nlay * 64 + threadIdx.x;
-  lw_solve_thread<BAND>(d, T, col, ig, scr, 64);
+  const int iw = grp * kLwGroup + threadIdx.y;
+  int b = 0;
+  while (b < kLwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
+  const int ig = iw - T.b[b].gs;
+  double *scr = d.scratch + ((long)tile * kLwNGpt + iw) * (long)LF_N * d.nlay * 64 + threadIdx.x;
+  switch (b + 1) {
+    case 1: lw_solve_thread<1>(d, T, col, ig, scr, 64); break;
+    case 2: lw_solve_thread<2>(d, T, col, ig, scr, 64); break;
+    case 3: lw_solve_thread<3>(d, T, col, ig, scr, 64); break;
+    case 4: lw_solve_thread<4>(d, T, col, ig, scr, 64); break;
+    case 5: lw_solve_thread<5>(d, T, col, ig, scr, 64); break;
+    case 6: lw_solve_thread<6>(d, T, col, ig, scr, 64); break;
+    case 7: lw_solve_thread<7>(d, T, col, ig, scr, 64); break;
+    case 8: lw_solve_thread<8>(d, T, col, ig, scr, 64); break;
+    case 9: lw_solve_thread<9>(d, T, col, ig, scr, 64); break;
+    case 10: lw_solve_thread<10>(d, T, col, ig, scr, 64); break;
+    case 11: lw_solve_thread<11>(d, T, col, ig, scr, 64); break;
+    case 12: lw_solve_thread<12>(d, T, col, ig, scr, 64); break;
+    case 13: lw_solve_thread<13>(d, T, col, ig, scr, 64); break;
+    case 14: lw_solve_thread<14>(d, T, col, ig, scr, 64); break;
+    case 15: lw_solve_thread<15>(d, T, col, ig, scr, 64); break;
+    default: lw_solve_thread<16>(d, T, col, ig, scr, 64); break;
+  }
 }
+
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y);
@@ -47,12 +73,6 @@ __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_heat_layer(d, T, col, blockIdx.y);
-}
-
-template <int BAND>
-static void launch_lw_solve(const LwDev &d, const LwTab &T, hipStream_t s) {
-  const int ntile = (d.ncol + 63) / 64;
-  hipLaunchKernelGGL(lw_solve_kernel<BAND>, dim3(ntile * T.b[BAND - 1].ng), dim3(64), 0, s, d, T);
 }
 
 void free_lw_desc(rrtmg_ctx *ctx) {
@@ -153,7 +173,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   }
   const int ntile = (N + 63) / 64;
   const int nk = d.idrv ? 6 : 4;
-  d.scratch = wd("scratch", (size_t)ntile * 16 * LF_N * L * 64);
+  d.scratch = wd("scratch", (size_t)ntile * kLwNGpt * LF_N * L * 64);
   d.part = wd("part", (size_t)kLwNGpt * nk * nl1);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
@@ -194,10 +214,13 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
     }
   }
-  launch_lw_solve<1>(d, T, s); launch_lw_solve<2>(d, T, s); launch_lw_solve<3>(d, T, s); launch_lw_solve<4>(d, T, s);
-  launch_lw_solve<5>(d, T, s); launch_lw_solve<6>(d, T, s); launch_lw_solve<7>(d, T, s); launch_lw_solve<8>(d, T, s);
-  launch_lw_solve<9>(d, T, s); launch_lw_solve<10>(d, T, s); launch_lw_solve<11>(d, T, s); launch_lw_solve<12>(d, T, s);
-  launch_lw_solve<13>(d, T, s); launch_lw_solve<14>(d, T, s); launch_lw_solve<15>(d, T, s); launch_lw_solve<16>(d, T, s);
+  {
+    const int ntile8 = (ntile + 7) / 8 * 8;
+    (void)hipEventRecord(ctx->ev[1][0], s);
+    hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile8 * (kLwNGpt / kLwGroup)), dim3(64, kLwGroup), 0, s, d, T, ntile8);
+    (void)hipEventRecord(ctx->ev[1][1], s);
+    ctx->ev_valid[1] = true;
+  }
   hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
   hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());

@@ -5,7 +5,7 @@
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
 //   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
 //   sw_kiss_kernel / mask upload (mcica)         sub-column cloud mask
-//   sw_solve_kernel<B>  14 launches, grid = tiles(64 columns) x ng(B), block = one wavefront
+//   sw_solve_all_kernel one launch: grid = tiles(64 columns) x 28 g-groups (XCD-aware), block = 4 wavefronts
 //   sw_flux_kernel      <<<ncol/64, nlay+1>>>    g-point sum per interface
 //   sw_heat_kernel      <<<ncol/64, nlay>>>      heating rates
 #include "rrtmg_ctx.h"
@@ -53,14 +53,41 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
   }
 }
 
-template <int BAND>
-__global__ void __launch_bounds__(64) sw_solve_kernel(SwDev d, SwTab T) {
-  const int ng = T.b[BAND - 16].ng;
-  const int tile = blockIdx.x / ng, ig = blockIdx.x - tile * ng;
+// All 112 g-points in ONE launch.  Block = 4 wavefronts = 4 consecutive g-points of one 64-column tile
+// (they share the tile's prep rows through L1); grid = 28 g-groups x tiles.  blockIdx -> (tile, group) is
+// XCD-aware: the dispatcher places block b on XCD b % 8, so every block of a tile is given the same
+// residue and the tile's prep arrays / k-table slices stay in ONE XCD's L2 (speed only, never correctness).
+constexpr int kSwGroup = 4;
+__global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8) {
+  const int q = blockIdx.x;
+  const int xcd = q & 7, r = q >> 3;
+  const int ngrp = kSwNGpt / kSwGroup;
+  const int grp = r % ngrp, tile = (r / ngrp) * 8 + xcd;
+  (void)ntile8;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + (long)blockIdx.x * F_NTOT * d.nlay * 64 + threadIdx.x;
-  sw_solve_thread<BAND>(d, T, col, ig, scr, 64);
+  const int iw = grp * kSwGroup + threadIdx.y;
+  // band of this wavefront's g-point (wave-uniform)
+  int b = 0;
+  while (b < kSwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
+  const int ig = iw - T.b[b].gs;
+  double *scr = d.scratch + ((long)tile * kSwNGpt + iw) * (long)F_NTOT * d.nlay * 64 + threadIdx.x;
+  switch (b + 16) {
+    case 16: sw_solve_thread<16>(d, T, col, ig, scr, 64); break;
+    case 17: sw_solve_thread<17>(d, T, col, ig, scr, 64); break;
+    case 18: sw_solve_thread<18>(d, T, col, ig, scr, 64); break;
+    case 19: sw_solve_thread<19>(d, T, col, ig, scr, 64); break;
+    case 20: sw_solve_thread<20>(d, T, col, ig, scr, 64); break;
+    case 21: sw_solve_thread<21>(d, T, col, ig, scr, 64); break;
+    case 22: sw_solve_thread<22>(d, T, col, ig, scr, 64); break;
+    case 23: sw_solve_thread<23>(d, T, col, ig, scr, 64); break;
+    case 24: sw_solve_thread<24>(d, T, col, ig, scr, 64); break;
+    case 25: sw_solve_thread<25>(d, T, col, ig, scr, 64); break;
+    case 26: sw_solve_thread<26>(d, T, col, ig, scr, 64); break;
+    case 27: sw_solve_thread<27>(d, T, col, ig, scr, 64); break;
+    case 28: sw_solve_thread<28>(d, T, col, ig, scr, 64); break;
+    default: sw_solve_thread<29>(d, T, col, ig, scr, 64); break;
+  }
 }
 
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d) {
@@ -70,13 +97,6 @@ __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d) {
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) sw_heat_layer(d, T, col, blockIdx.y);
-}
-
-template <int BAND>
-static void launch_solve(const SwDev &d, const SwTab &T, hipStream_t s) {
-  const int ntile = (d.ncol + 63) / 64;
-  const int ng = T.b[BAND - 16].ng;
-  hipLaunchKernelGGL(sw_solve_kernel<BAND>, dim3(ntile * ng), dim3(64), 0, s, d, T);
 }
 
 void free_sw_desc(rrtmg_ctx *ctx) {
@@ -219,7 +239,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
-  d.scratch = wd("scratch", (size_t)ntile * 12 * F_NTOT * L * 64);
+  d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
   d.part = wd("part", (size_t)kSwNGpt * 4 * nl1);
   if (a->memspace == 1) {
     d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
@@ -260,10 +280,13 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       }
     }
   }
-  launch_solve<16>(d, T, s); launch_solve<17>(d, T, s); launch_solve<18>(d, T, s); launch_solve<19>(d, T, s);
-  launch_solve<20>(d, T, s); launch_solve<21>(d, T, s); launch_solve<22>(d, T, s); launch_solve<23>(d, T, s);
-  launch_solve<24>(d, T, s); launch_solve<25>(d, T, s); launch_solve<26>(d, T, s); launch_solve<27>(d, T, s);
-  launch_solve<28>(d, T, s); launch_solve<29>(d, T, s);
+  {
+    const int ntile8 = (ntile + 7) / 8 * 8;
+    (void)hipEventRecord(ctx->ev[0][0], s);
+    hipLaunchKernelGGL(sw_solve_all_kernel, dim3(ntile8 * (kSwNGpt / kSwGroup)), dim3(64, kSwGroup), 0, s, d, T, ntile8);
+    (void)hipEventRecord(ctx->ev[0][1], s);
+    ctx->ev_valid[0] = true;
+  }
   hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d);
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());

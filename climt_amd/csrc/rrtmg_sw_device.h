@@ -327,6 +327,7 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
 // ------------------------------------------------------------------------------------------
 struct Kiss { int32_t s1, s2, s3, s4; };
 RRTMG_HD double kiss_next(Kiss &k) {
+#pragma clang fp contract(off)   // kiss*2.328306e-10 + 0.5 is compared with 1-cldf: keep the reference's rounding
   uint32_t a = (uint32_t)k.s1, b = (uint32_t)k.s2, c = (uint32_t)k.s3, e = (uint32_t)k.s4;
   a = 69069u * a + 1327217885u;
   b ^= b << 13; b ^= b >> 17; b ^= b << 5;
@@ -348,6 +349,9 @@ RRTMG_HD void kiss_mask_column(int ncol, int nlay, int nsub, int icld, int chang
   if (L < 4) { report_error(err, 4); return; }
   Kiss k;
   {
+    // integer seeds come from the fractional part of pmid = play*100: the product must be ROUNDED before the
+    // subtraction (as the reference, which stores pmid), so no fused multiply-add here
+#pragma clang fp contract(off)
     const double p1 = play[col] * 1.e2, p2 = play[(long)N + col] * 1.e2;
     const double p3 = play[2l * N + col] * 1.e2, p4 = play[3l * N + col] * 1.e2;
     if (p1 < p2) { report_error(err, 14); return; }

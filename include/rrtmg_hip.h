@@ -75,6 +75,9 @@ const char *rrtmg_hip_version(void);
 /* HIP stream (hipStream_t) all work of this context is enqueued on; for event timing. */
 void *rrtmg_hip_stream(rrtmg_ctx *ctx);
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
+/* Duration (ms, HIP events recorded on the context's stream) of the dominant kernel of the last completed
+ * call: which = 0 -> sw_solve_all_kernel, 1 -> lw_solve_all_kernel.  Returns RRTMG_ERR_ARG if never run. */
+int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
 
 /* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz,
