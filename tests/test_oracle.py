@@ -1,0 +1,84 @@
+"""CPU tests that PIN THE ORACLE (oracle/ plain-C restatement) before anything is checked against it:
+the reference's post-init tables, reference-Fortran outputs on seeded columns, the reference's own golden
+caches (shortwave), and -- when oracle/_ref is present -- the live reference library."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, REF_CASES, load_cache_case, load_ref_case, maxdiff
+from oracle import port_driver as port
+
+
+@pytest.mark.parametrize("which", ["sw", "lw"])
+def test_oracle_tables_match_reference_init(which):
+    fx = np.load(os.path.join(GOLDEN, "%s_reduced_tables.npz" % which))
+    n = 0
+    for key in fx.files:
+        name = key.replace("__", "/")
+        if name.endswith("con/heatfac"):
+            continue
+        mine = port.table(name)
+        assert np.array_equal(mine, np.asarray(fx[key]).ravel(order="F")), name
+        n += 1
+    assert n > 100
+
+
+@pytest.mark.parametrize("case", REF_CASES)
+def test_oracle_sw_matches_reference_fortran(case):
+    c, mcica, exp = load_ref_case(case)
+    out = port.PortSW().fluxes(c, mcica=mcica)
+    for k, v in exp["sw"].items():
+        assert maxdiff(out[k], v) <= 1e-9, (k, maxdiff(out[k], v))
+
+
+@pytest.mark.parametrize("case", REF_CASES)
+def test_oracle_lw_matches_reference_fortran_on_synthetic_tables(case):
+    c, mcica, exp = load_ref_case(case)
+    c = dict(c)
+    if not mcica:
+        c["icld"] = 1
+    out = port.PortLW().fluxes(c, mcica=mcica)
+    for k, v in exp["lw"].items():
+        assert maxdiff(out[k], v) <= 1e-9, (k, maxdiff(out[k], v))
+
+
+def test_oracle_sw_reproduces_reference_golden_cache():
+    """TestRRTMGShortwave-column: the reference's own regression vector, |d| <= 1e-8."""
+    from climt_amd._util import get_interface_values
+    state, tend, diag = load_cache_case("TestRRTMGShortwave", "column")
+    col = lambda n, f=1.0: np.asarray(state[n].values, dtype=float).reshape(state[n].values.shape[0], -1) * f
+    flat = lambda n: np.asarray(state[n].values, dtype=float).reshape(-1)
+    p, pi, t = col("air_pressure"), col("air_pressure_on_interface_levels"), col("air_temperature")
+    inp = dict(play=p / 100, plev=pi / 100, tlay=t, tlev=get_interface_values(t, flat("surface_temperature"), p, pi), tsfc=flat("surface_temperature"),
+               h2o=col("specific_humidity") * 28.964 / 18.02, o3=col("mole_fraction_of_ozone_in_air"), co2=col("mole_fraction_of_carbon_dioxide_in_air"),
+               ch4=col("mole_fraction_of_methane_in_air"), n2o=col("mole_fraction_of_nitrous_oxide_in_air"), o2=col("mole_fraction_of_oxygen_in_air"),
+               asdir=flat("surface_albedo_for_direct_shortwave"), asdif=flat("surface_albedo_for_diffuse_shortwave"),
+               aldir=flat("surface_albedo_for_direct_near_infrared"), aldif=flat("surface_albedo_for_diffuse_near_infrared"),
+               coszen=np.cos(flat("zenith_angle")), cldfr=col("cloud_area_fraction_in_atmosphere_layer"), cicewp=col("mass_content_of_cloud_ice_in_atmosphere_layer", 1000.0),
+               cliqwp=col("mass_content_of_cloud_liquid_water_in_atmosphere_layer", 1000.0), reice=col("cloud_ice_particle_size"), reliq=col("cloud_water_droplet_radius"),
+               icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1)
+    out = port.PortSW().fluxes(inp)
+    exp = diag["upwelling_shortwave_flux_in_air"].values.reshape(out["swuflx"].shape)
+    assert maxdiff(out["swuflx"], exp) <= 1e-8
+    assert maxdiff(out["swhr"], tend["air_temperature"].values.reshape(out["swhr"].shape)) <= 1e-8
+
+
+def test_oracle_against_live_reference_library():
+    from oracle import ref_driver
+    if not (ref_driver.available("sw") and ref_driver.available("lw")):
+        pytest.skip("oracle/_ref not built here")
+    from climt_amd.synthetic import make_columns
+    from tools.pack_tables import read_blob
+    from tools.synth_lw_tables import fill_reference_from_blob
+    c = make_columns(40, 45, cloudy=True, seed=321)
+    c.update(icld=2, iaer=0, dyofyr=80, scon=1361.0, isolvar=0, inflg=2, iceflg=3, liqflg=1, irng=0, permuteseed=7, adjes=1.0)
+    r = ref_driver.RefSW().fluxes(c, mcica=True)
+    o = port.PortSW().fluxes(c, mcica=True)
+    assert max(maxdiff(o[k], r[k]) for k in o) <= 1e-9
+    blob = read_blob(port.LW_BLOB)
+    rl = ref_driver.RefLW(); rl.init(fill_tables=lambda x: fill_reference_from_blob(x, blob))
+    c["idrv"] = 1
+    r = rl.fluxes(c, mcica=True)
+    o = port.PortLW().fluxes(c, mcica=True)
+    assert max(maxdiff(o[k], r[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")) <= 1e-9
