@@ -33,7 +33,41 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 }
 // All 140 g-points in ONE launch; same (tile, g-group) -> XCD mapping as the shortwave (rrtmg_sw.hip).
 constexpr int kLwGroup = 4;
+
+// Block-reducing radiance sink (see SwBlockSink): the 4 wavefronts of a block add their band-weighted radiances
+// through LDS; wave k reduces quantity k.  One __syncthreads per emit, double-buffered by call parity.
+struct LwBlockSink {
+  double (*sh)[kLwGroup][4][64];
+  double *p;     // part + (grp*nk*(L+1))*N + col
+  long N, st;
+  int wave, lane, phase;
+  bool idrv;
+  __device__ void reduce_store(int k, int slot, int lev) {
+    double s = sh[phase][0][slot][lane];
+    s = s + sh[phase][1][slot][lane]; s = s + sh[phase][2][slot][lane]; s = s + sh[phase][3][slot][lane];
+    p[k * st + (long)lev * N] = s;
+  }
+  __device__ void dn(int lev, double rd, double rcd) {
+    sh[phase][wave][0][lane] = rd; sh[phase][wave][1][lane] = rcd;
+    __syncthreads();
+    if (wave == 0) reduce_store(1, 0, lev);
+    if (wave == 1) reduce_store(3, 1, lev);
+    phase ^= 1;
+  }
+  __device__ void up(int lev, double ru, double rcu, double du, double dcu) {
+    sh[phase][wave][0][lane] = ru; sh[phase][wave][1][lane] = rcu;
+    if (idrv) { sh[phase][wave][2][lane] = du; sh[phase][wave][3][lane] = dcu; }
+    __syncthreads();
+    if (wave == 0) reduce_store(0, 0, lev);
+    if (wave == 1) reduce_store(2, 1, lev);
+    if (idrv && wave == 2) reduce_store(4, 2, lev);
+    if (idrv && wave == 3) reduce_store(5, 3, lev);
+    phase ^= 1;
+  }
+};
+
 __global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8) {
+  __shared__ double sh[2][kLwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
   const int ngrp = kLwNGpt / kLwGroup;
@@ -46,29 +80,33 @@ __global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int
   while (b < kLwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
   const int ig = iw - T.b[b].gs;
   double *scr = d.scratch + ((long)tile * kLwNGpt + iw) * (long)LF_N * d.nlay * 64 + threadIdx.x;
+  LwBlockSink sink;
+  sink.sh = sh; sink.N = d.ncol; sink.st = (long)(d.nlay + 1) * d.ncol; sink.wave = threadIdx.y; sink.lane = threadIdx.x;
+  sink.phase = 0; sink.idrv = d.idrv != 0;
+  sink.p = d.part + ((long)grp * (d.idrv ? 6 : 4) * (d.nlay + 1)) * d.ncol + col;
   switch (b + 1) {
-    case 1: lw_solve_thread<1>(d, T, col, ig, scr, 64); break;
-    case 2: lw_solve_thread<2>(d, T, col, ig, scr, 64); break;
-    case 3: lw_solve_thread<3>(d, T, col, ig, scr, 64); break;
-    case 4: lw_solve_thread<4>(d, T, col, ig, scr, 64); break;
-    case 5: lw_solve_thread<5>(d, T, col, ig, scr, 64); break;
-    case 6: lw_solve_thread<6>(d, T, col, ig, scr, 64); break;
-    case 7: lw_solve_thread<7>(d, T, col, ig, scr, 64); break;
-    case 8: lw_solve_thread<8>(d, T, col, ig, scr, 64); break;
-    case 9: lw_solve_thread<9>(d, T, col, ig, scr, 64); break;
-    case 10: lw_solve_thread<10>(d, T, col, ig, scr, 64); break;
-    case 11: lw_solve_thread<11>(d, T, col, ig, scr, 64); break;
-    case 12: lw_solve_thread<12>(d, T, col, ig, scr, 64); break;
-    case 13: lw_solve_thread<13>(d, T, col, ig, scr, 64); break;
-    case 14: lw_solve_thread<14>(d, T, col, ig, scr, 64); break;
-    case 15: lw_solve_thread<15>(d, T, col, ig, scr, 64); break;
-    default: lw_solve_thread<16>(d, T, col, ig, scr, 64); break;
+    case 1: lw_solve_thread<1>(d, T, col, ig, scr, 64, sink); break;
+    case 2: lw_solve_thread<2>(d, T, col, ig, scr, 64, sink); break;
+    case 3: lw_solve_thread<3>(d, T, col, ig, scr, 64, sink); break;
+    case 4: lw_solve_thread<4>(d, T, col, ig, scr, 64, sink); break;
+    case 5: lw_solve_thread<5>(d, T, col, ig, scr, 64, sink); break;
+    case 6: lw_solve_thread<6>(d, T, col, ig, scr, 64, sink); break;
+    case 7: lw_solve_thread<7>(d, T, col, ig, scr, 64, sink); break;
+    case 8: lw_solve_thread<8>(d, T, col, ig, scr, 64, sink); break;
+    case 9: lw_solve_thread<9>(d, T, col, ig, scr, 64, sink); break;
+    case 10: lw_solve_thread<10>(d, T, col, ig, scr, 64, sink); break;
+    case 11: lw_solve_thread<11>(d, T, col, ig, scr, 64, sink); break;
+    case 12: lw_solve_thread<12>(d, T, col, ig, scr, 64, sink); break;
+    case 13: lw_solve_thread<13>(d, T, col, ig, scr, 64, sink); break;
+    case 14: lw_solve_thread<14>(d, T, col, ig, scr, 64, sink); break;
+    case 15: lw_solve_thread<15>(d, T, col, ig, scr, 64, sink); break;
+    default: lw_solve_thread<16>(d, T, col, ig, scr, 64, sink); break;
   }
 }
 
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y);
+  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, kLwNGpt / kLwGroup);
 }
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -174,7 +212,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const int ntile = (N + 63) / 64;
   const int nk = d.idrv ? 6 : 4;
   d.scratch = wd("scratch", (size_t)ntile * kLwNGpt * LF_N * L * 64);
-  d.part = wd("part", (size_t)kLwNGpt * nk * nl1);
+  d.part = wd("part", (size_t)(kLwNGpt / kLwGroup) * nk * nl1);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
   if (a->memspace == 1) {

@@ -689,9 +689,31 @@ RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
 
 enum { LF_ATRANS = 0, LF_BBUGAS, LF_ATOT, LF_BBUTOT, LF_N };
 
-// One (column, g-point): rtrn / rtrnmc for this g-point (rrtmg_lw_rtrn.f90:324-525).
-template <int BAND>
-RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, double *scr, long stride) {
+// Per-g-point radiance sink used by the host emulation: band-weighted radiances of every g-point go to
+// part[g][k][level][column], k = 0 up, 1 down, 2 clear up, 3 clear down, (4, 5 = d/dTs of 0, 2 with idrv).
+// The device kernel uses a block-reducing sink instead (rrtmg_lw.hip).
+struct LwPartSink {
+  double *p;       // part + (iw*nk*(L+1))*N + col
+  long N, st;      // st = (L+1)*N
+  bool idrv;
+  RRTMG_HD void dn(int lev, double rd, double rcd) { p[st + (long)lev * N] = rd; p[3 * st + (long)lev * N] = rcd; }
+  RRTMG_HD void up(int lev, double ru, double rcu, double du, double dcu) {
+    p[(long)lev * N] = ru; p[2 * st + (long)lev * N] = rcu;
+    if (idrv) { p[4 * st + (long)lev * N] = du; p[5 * st + (long)lev * N] = dcu; }
+  }
+};
+RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int iw, int col) {
+  LwPartSink s;
+  const int nk = d.idrv ? 6 : 4;
+  s.N = d.ncol; s.st = (long)(d.nlay + 1) * d.ncol; s.idrv = d.idrv != 0;
+  s.p = d.part + ((long)iw * nk * (d.nlay + 1)) * d.ncol + col;
+  return s;
+}
+
+// One (column, g-point): rtrn / rtrnmc for this g-point (rrtmg_lw_rtrn.f90:324-525).  Radiances leave through
+// `sink` already weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543), so partial sums may span bands.
+template <int BAND, class Sink>
+RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
   const int ib = BAND - 1;
   const int iw = T.b[ib].gs + ig;
@@ -700,9 +722,10 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
   const double rec_6 = 0.166667;
   const int laytrop = d.laytrop[col];
   const double secd = d.secdiff[(long)ib * N + col];
-  const int nk = d.idrv ? 6 : 4;
+  const double wtdiff = 0.5, delw = t[T.delwave + ib];
+  (void)iw;
   auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
-  auto P = [&](int k, int lev) -> double & { return d.part[(((long)iw * nk + k) * (L + 1) + lev) * N + col]; };
+  auto W = [&](double r) { return (r * wtdiff) * delw; };
 
   // cloud bookkeeping
   const bool clouds = d.icld >= 1 && d.cldfr != nullptr;
@@ -724,8 +747,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
   double radld = 0.0, radclrd = 0.0;
   int iclddn = 0;
   double plfrac_bot = 0.0;
-  P(1, L) = 0.0;
-  P(3, L) = 0.0;
+  sink.dn(L, 0.0, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
   for (int lev = L; lev >= 1; --lev) {
     const int l = lev - 1;
@@ -748,8 +770,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
     double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
     if (clouds) {
       if (d.mcica) {
-        icldlyr = (aw[l >> 6] >> (l & 63)) & 1ull;
-        if ((mw[l >> 6] >> (l & 63)) & 1ull) {
+        icldlyr = mask_bit(aw, l);
+        if (mask_bit(mw, l)) {
           cfrac = 1.0;
           odcld = secd * d.ctau[((long)ib * L + l) * N + col];
           const double transcld = exp(-odcld);
@@ -832,13 +854,12 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
     }
     S(LF_ATRANS, l) = atrans;
     S(LF_BBUGAS, l) = bbugas;
-    P(1, lev - 1) = radld;
     if (iclddn == 1) {
       radclrd = radclrd + (bbd - radclrd) * atrans;
     } else {
       radclrd = radld;
     }
-    P(3, lev - 1) = radclrd;
+    sink.dn(lev - 1, W(radld), W(radclrd));
     plfrac_bot = plfrac;
   }
 
@@ -850,14 +871,12 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
   const double reflect = 1.0 - semiss;
   double radlu = rad0 + reflect * radld;
   double radclru = rad0 + reflect * radclrd;
-  P(0, 0) = radlu;
-  P(2, 0) = radclru;
   double d_radlu_dt = 0.0, d_radclru_dt = 0.0;
   if (d.idrv) {
     const double d_rad0_dt = plfrac_bot * (semiss * lw_planck_deriv(T, ib, tbound));
     d_radlu_dt = d_rad0_dt; d_radclru_dt = d_rad0_dt;
-    P(4, 0) = d_radlu_dt; P(5, 0) = d_radclru_dt;
   }
+  sink.up(0, W(radlu), W(radclru), W(d_radlu_dt), W(d_radclru_dt));
 
   // ---- upward sweep ---------------------------------------------------------------------------
   for (int lev = 1; lev <= L; ++lev) {
@@ -867,8 +886,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
     double cfrac = 0.0, efclfrac = 0.0;
     if (clouds) {
       if (d.mcica) {
-        icldlyr = (aw[l >> 6] >> (l & 63)) & 1ull;
-        if ((mw[l >> 6] >> (l & 63)) & 1ull) {
+        icldlyr = mask_bit(aw, l);
+        if (mask_bit(mw, l)) {
           cfrac = 1.0;
           const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
           efclfrac = (1.0 - exp(-odcld)) * cfrac;
@@ -891,7 +910,6 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
       radlu = radlu + (bbugas - radlu) * atrans;
       if (d.idrv) d_radlu_dt = d_radlu_dt * (1.0 - atrans);
     }
-    P(0, lev) = radlu;
     if (iclddn == 1) {
       radclru = radclru + (bbugas - radclru) * atrans;
       if (d.idrv) d_radclru_dt = d_radclru_dt * (1.0 - atrans);
@@ -899,38 +917,28 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
       radclru = radlu;
       if (d.idrv) d_radclru_dt = d_radlu_dt;
     }
-    P(2, lev) = radclru;
-    if (d.idrv) { P(4, lev) = d_radlu_dt; P(5, lev) = d_radclru_dt; }
+    sink.up(lev, W(radlu), W(radclru), W(d_radlu_dt), W(d_radclru_dt));
   }
 }
 
 // band / g-point integration and heating rates (rrtmg_lw_rtrn.f90:528-585)
 // one thread per (column, interface level)
-RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev) {
+// nparts = 140 (per-g-point partials, host emulation) or 35 (block-reduced partials of the device kernel);
+// the partials already carry wtdiff*delwave(band)
+RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts) {
+  (void)T;
   const int L = d.nlay, N = d.ncol;
   const int nk = d.idrv ? 6 : 4;
-  const double wtdiff = 0.5;
-  const double *delwave = T.t + T.delwave;
   const long st = (long)(L + 1) * N;
-  double tot[6] = {0, 0, 0, 0, 0, 0};
-  for (int b = 0; b < kLwNBand; ++b) {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0;
-    const int g0 = T.b[b].gs, g1 = g0 + T.b[b].ng;
-    for (int iw = g0; iw < g1; ++iw) {
-      const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * N + col;
-      a0 = a0 + p[0]; a1 = a1 + p[st]; a2 = a2 + p[2 * st]; a3 = a3 + p[3 * st];
-      if (d.idrv) { a4 = a4 + p[4 * st]; a5 = a5 + p[5 * st]; }
-    }
-    tot[0] = tot[0] + (a0 * wtdiff) * delwave[b]; tot[1] = tot[1] + (a1 * wtdiff) * delwave[b];
-    tot[2] = tot[2] + (a2 * wtdiff) * delwave[b]; tot[3] = tot[3] + (a3 * wtdiff) * delwave[b];
-    if (d.idrv) {
-      tot[4] = tot[4] + (a4 * wtdiff) * delwave[b] * d.fluxfac;
-      tot[5] = tot[5] + (a5 * wtdiff) * delwave[b] * d.fluxfac;
-    }
+  double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
+  for (int iw = 0; iw < nparts; ++iw) {
+    const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * N + col;
+    t0 = t0 + p[0]; t1 = t1 + p[st]; t2 = t2 + p[2 * st]; t3 = t3 + p[3 * st];
+    if (d.idrv) { t4 = t4 + p[4 * st]; t5 = t5 + p[5 * st]; }
   }
   const long o = (long)lev * N + col;
-  d.uflx[o] = tot[0] * d.fluxfac; d.dflx[o] = tot[1] * d.fluxfac; d.uflxc[o] = tot[2] * d.fluxfac; d.dflxc[o] = tot[3] * d.fluxfac;
-  if (d.idrv) { d.duflx_dt[o] = tot[4]; d.duflxc_dt[o] = tot[5]; }
+  d.uflx[o] = t0 * d.fluxfac; d.dflx[o] = t1 * d.fluxfac; d.uflxc[o] = t2 * d.fluxfac; d.dflxc[o] = t3 * d.fluxfac;
+  if (d.idrv) { d.duflx_dt[o] = t4 * d.fluxfac; d.duflxc_dt[o] = t5 * d.fluxfac; }
 }
 // one thread per (column, layer)
 RRTMG_HD void lw_heat_layer(const LwDev &d, const LwTab &T, int col, int lay) {

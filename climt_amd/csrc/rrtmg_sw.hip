@@ -58,7 +58,28 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 // XCD-aware: the dispatcher places block b on XCD b % 8, so every block of a tile is given the same
 // residue and the tile's prep arrays / k-table slices stay in ONE XCD's L2 (speed only, never correctness).
 constexpr int kSwGroup = 4;
+
+// Flux sink of the device kernel: the 4 wavefronts (g-points) of a block add their weighted fluxes through LDS
+// at every interface and the block writes ONE partial per quantity -- part[g-group][k][level][column] -- so the
+// spectral integration reads 28 instead of 112 partials.  Fixed summation order -> deterministic, shard-exact.
+// Double-buffered by level parity: one __syncthreads per level.
+struct SwBlockSink {
+  double (*sh)[kSwGroup][4][64];
+  double *out;   // part + ((grp*4 + wave) * (L+1)) * N + col  (wave w reduces quantity k = w)
+  long N;
+  int wave, lane;
+  __device__ void emit(int lev, double fu, double fd, double cu, double cd) {
+    const int pb = lev & 1;
+    sh[pb][wave][0][lane] = fu; sh[pb][wave][1][lane] = fd; sh[pb][wave][2][lane] = cu; sh[pb][wave][3][lane] = cd;
+    __syncthreads();
+    double s = sh[pb][0][wave][lane];
+    s = s + sh[pb][1][wave][lane]; s = s + sh[pb][2][wave][lane]; s = s + sh[pb][3][wave][lane];
+    out[(long)lev * N] = s;
+  }
+};
+
 __global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8) {
+  __shared__ double sh[2][kSwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
   const int ngrp = kSwNGpt / kSwGroup;
@@ -72,27 +93,30 @@ __global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int
   while (b < kSwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
   const int ig = iw - T.b[b].gs;
   double *scr = d.scratch + ((long)tile * kSwNGpt + iw) * (long)F_NTOT * d.nlay * 64 + threadIdx.x;
+  SwBlockSink sink;
+  sink.sh = sh; sink.N = d.ncol; sink.wave = threadIdx.y; sink.lane = threadIdx.x;
+  sink.out = d.part + (((long)grp * 4 + threadIdx.y) * (d.nlay + 1)) * d.ncol + col;
   switch (b + 16) {
-    case 16: sw_solve_thread<16>(d, T, col, ig, scr, 64); break;
-    case 17: sw_solve_thread<17>(d, T, col, ig, scr, 64); break;
-    case 18: sw_solve_thread<18>(d, T, col, ig, scr, 64); break;
-    case 19: sw_solve_thread<19>(d, T, col, ig, scr, 64); break;
-    case 20: sw_solve_thread<20>(d, T, col, ig, scr, 64); break;
-    case 21: sw_solve_thread<21>(d, T, col, ig, scr, 64); break;
-    case 22: sw_solve_thread<22>(d, T, col, ig, scr, 64); break;
-    case 23: sw_solve_thread<23>(d, T, col, ig, scr, 64); break;
-    case 24: sw_solve_thread<24>(d, T, col, ig, scr, 64); break;
-    case 25: sw_solve_thread<25>(d, T, col, ig, scr, 64); break;
-    case 26: sw_solve_thread<26>(d, T, col, ig, scr, 64); break;
-    case 27: sw_solve_thread<27>(d, T, col, ig, scr, 64); break;
-    case 28: sw_solve_thread<28>(d, T, col, ig, scr, 64); break;
-    default: sw_solve_thread<29>(d, T, col, ig, scr, 64); break;
+    case 16: sw_solve_thread<16>(d, T, col, ig, scr, 64, sink); break;
+    case 17: sw_solve_thread<17>(d, T, col, ig, scr, 64, sink); break;
+    case 18: sw_solve_thread<18>(d, T, col, ig, scr, 64, sink); break;
+    case 19: sw_solve_thread<19>(d, T, col, ig, scr, 64, sink); break;
+    case 20: sw_solve_thread<20>(d, T, col, ig, scr, 64, sink); break;
+    case 21: sw_solve_thread<21>(d, T, col, ig, scr, 64, sink); break;
+    case 22: sw_solve_thread<22>(d, T, col, ig, scr, 64, sink); break;
+    case 23: sw_solve_thread<23>(d, T, col, ig, scr, 64, sink); break;
+    case 24: sw_solve_thread<24>(d, T, col, ig, scr, 64, sink); break;
+    case 25: sw_solve_thread<25>(d, T, col, ig, scr, 64, sink); break;
+    case 26: sw_solve_thread<26>(d, T, col, ig, scr, 64, sink); break;
+    case 27: sw_solve_thread<27>(d, T, col, ig, scr, 64, sink); break;
+    case 28: sw_solve_thread<28>(d, T, col, ig, scr, 64, sink); break;
+    default: sw_solve_thread<29>(d, T, col, ig, scr, 64, sink); break;
   }
 }
 
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y);
+  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y, kSwNGpt / kSwGroup);
 }
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -240,7 +264,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
   d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
-  d.part = wd("part", (size_t)kSwNGpt * 4 * nl1);
+  d.part = wd("part", (size_t)(kSwNGpt / kSwGroup) * 4 * nl1);
   if (a->memspace == 1) {
     d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   } else {

@@ -664,116 +664,152 @@ RRTMG_HD double sw_incflux(const SwDev &d, const SwTab &T, int col, int ig, doub
   return d.adjflux * s * prmu0;
 }
 
-enum { F_REF = 0, F_REFD, F_TRA, F_TRAD, F_DBT, F_RUP, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
+enum { F_RUP = 0, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
 
-// One (column, g-point): both sweeps.  scr -> this thread's element of a [field][layer][stride] slab.
+// optical properties of one layer for one g-point: clear sky and (if requested) total sky
+struct SwLayerOpt { double ref, refd, tra, trad, dbt; };
+
+// Per-g-point flux sink used by the host emulation and by tests: weighted (fu, fd, cu, cd) of every g-point go
+// to part[g][k][level][column]; the device kernel uses a block-reducing sink instead (rrtmg_sw.hip).
+struct SwPartSink {
+  double *pfu, *pfd, *pcu, *pcd;
+  long N;
+  RRTMG_HD void emit(int lev, double fu, double fd, double cu, double cd) {
+    pfu[(long)lev * N] = fu; pfd[(long)lev * N] = fd; pcu[(long)lev * N] = cu; pcd[(long)lev * N] = cd;
+  }
+};
+RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int iw, int col) {
+  const long N = d.ncol, L1 = d.nlay + 1;
+  SwPartSink s;
+  s.N = N;
+  s.pfu = d.part + (((long)iw * 4 + 0) * L1) * N + col; s.pfd = d.part + (((long)iw * 4 + 1) * L1) * N + col;
+  s.pcu = d.part + (((long)iw * 4 + 2) * L1) * N + col; s.pcd = d.part + (((long)iw * 4 + 3) * L1) * N + col;
+  return s;
+}
+
+// per-thread constants of a (column, g-point)
+struct SwThreadCtx {
+  int b, iw, ig, laytrop;
+  double prmu0;
+  bool cloudy_col;
+  uint64_t mw[4];
+};
+
+// taumol + delta scaling + reftra (+ cloud) for layer l: everything the two adding-method sweeps need.
+// Called in BOTH sweeps: recomputing it is cheaper than spilling five more level arrays through HBM
+// (the kernel was HBM-bound on that scratch traffic: profiles/r01_pmc_*.txt).
 template <int BAND>
-RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, double *scr, long stride) {
+RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx &c, int col, int l, SwLayerOpt &clr, SwLayerOpt &tot) {
   const int L = d.nlay, N = d.ncol;
-  const int b = BAND - 16;
-  const int iw = T.b[b].gs + ig;
   const double *exp_tbl = T.t + T.exp_tbl;
-  const double prmu0 = d.cossza[col];
-  const int laytrop = d.laytrop[col];
-  const double zinc = sw_incflux<BAND>(d, T, col, ig, prmu0);
+  const double prmu0 = c.prmu0;
+  const long i = (long)l * N + col;
+  SwLayerIn s;
+  sw_load_layer(d, i, s);
+  double taur;
+  const double taug = sw_taug<BAND>(T, s, (l + 1) <= c.laytrop, c.ig, taur);
+  double taua = 0.0, omga = 1.0, asya = 0.0;
+  if (d.tauaer) {
+    const long o = ((long)c.b * L + l) * N + col;
+    taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o];
+  }
+  // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
+  double ztauc = taur + taug + taua;
+  double zomcc = taur * 1.0 + taua * omga;
+  double zgcc = asya * omga * taua / zomcc;
+  zomcc = zomcc / ztauc;
+  {
+    const double zf = zgcc * zgcc, zwf = zomcc * zf;
+    ztauc = (1.0 - zwf) * ztauc;
+    zomcc = (zomcc - zwf) / (1.0 - zwf);
+    zgcc = (zgcc - zf) / (1.0 - zf);
+  }
+  sw_reftra(exp_tbl, zgcc, prmu0, ztauc, zomcc, clr.ref, clr.refd, clr.tra, clr.trad);
+  clr.dbt = sw_dbt(exp_tbl, ztauc, prmu0);
+  if (!c.cloudy_col) return;
+  tot = clr;
+  bool lcld;
+  double zcloud;
+  if (d.mcica) { lcld = mask_bit(c.mw, l); zcloud = lcld ? 1.0 : 0.0; }
+  else { zcloud = d.cldfr[i]; lcld = zcloud > 1.e-12; }
+  const long o = ((long)c.b * L + l) * N + col;
+  const double ptauc = (lcld || !d.mcica) ? d.ctau[o] : 0.0;
+  if (lcld) {
+    const double pomgc = d.cssa[o], pasyc = d.casm[o];
+    // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
+    const double ztauo = ztauc + ptauc;
+    double zomco = ztauc * zomcc + ptauc * pomgc;
+    const double zgco = (ptauc * pomgc * pasyc + ztauc * zomcc * zgcc) / zomco;
+    zomco = zomco / ztauo;
+    double refo, refdo, trao, trado;
+    sw_reftra(exp_tbl, zgco, prmu0, ztauo, zomco, refo, refdo, trao, trado);
+    const double dbto = sw_dbt(exp_tbl, ztauo, prmu0);
+    if (d.mcica) {
+      tot.ref = refo; tot.refd = refdo; tot.tra = trao; tot.trad = trado; tot.dbt = dbto;
+    } else {
+      const double zclear = 1.0 - zcloud;
+      tot.ref = zclear * clr.ref + zcloud * refo; tot.refd = zclear * clr.refd + zcloud * refdo;
+      tot.tra = zclear * clr.tra + zcloud * trao; tot.trad = zclear * clr.trad + zcloud * trado;
+      tot.dbt = zclear * clr.dbt + zcloud * dbto;
+    }
+  } else if (!d.mcica && zcloud != 0.0) {
+    // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
+    const double zclear = 1.0 - zcloud;
+    const double dbto = sw_dbt(exp_tbl, ztauc + ptauc, prmu0);
+    tot.ref = zclear * clr.ref; tot.refd = zclear * clr.refd; tot.tra = zclear * clr.tra + zcloud; tot.trad = zclear * clr.trad + zcloud;
+    tot.dbt = zclear * clr.dbt + zcloud * dbto;
+  }
+}
+
+// One (column, g-point): both sweeps.  scr -> this thread's element of a [field][layer][stride] slab holding the
+// upward-sweep results (rup, rupd) for the clear and -- in cloudy columns -- the total sky.
+template <int BAND, class Sink>
+RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, double *scr, long stride, Sink &sink) {
+  const int L = d.nlay, N = d.ncol;
+  SwThreadCtx c;
+  c.b = BAND - 16;
+  c.ig = ig;
+  c.iw = T.b[c.b].gs + ig;
+  c.prmu0 = d.cossza[col];
+  c.laytrop = d.laytrop[col];
+  const double zinc = sw_incflux<BAND>(d, T, col, ig, c.prmu0);
   // albedo by band: bands 1-9 and 14 near-IR, 10-13 UV/vis (rrtmg_sw_rad.nomcica.f90:648-659)
-  const bool vis = (b >= 9 && b <= 12);
+  const bool vis = (c.b >= 9 && c.b <= 12);
   const double albp = vis ? d.asdir[col] : d.aldir[col];
   const double albd = vis ? d.asdif[col] : d.aldif[col];
-  // cloud presence for this thread
-  bool cloudy_col = false;
-  uint64_t mw[4] = {0, 0, 0, 0};
+  c.cloudy_col = false;
+  c.mw[0] = c.mw[1] = c.mw[2] = c.mw[3] = 0;
   if (d.icld >= 1) {
     if (d.mcica) {
-      for (int w = 0; w < d.nw && w < 4; ++w) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; cloudy_col |= (mw[w] != 0); }
+      for (int w = 0; w < d.nw && w < 4; ++w) { c.mw[w] = d.mask[((long)c.iw * d.nw + w) * N + col]; c.cloudy_col |= (c.mw[w] != 0); }
     } else {
-      cloudy_col = d.anycld[col] != 0;
+      c.cloudy_col = d.anycld[col] != 0;
     }
   }
   auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
 
-  // ---- sweep 1: bottom -> top ---------------------------------------------------------------
+  // ---- sweep 1: bottom -> top, upward adding recurrence (rrtmg_sw_vrtqdr.f90:114-140) ---------------
   double rupc = albp, rupdc = albd, rup = albp, rupd = albd;
   for (int l = 0; l < L; ++l) {
-    const long i = (long)l * N + col;
-    SwLayerIn s;
-    sw_load_layer(d, i, s);
-    double taur;
-    const double taug = sw_taug<BAND>(T, s, (l + 1) <= laytrop, ig, taur);
-    double taua = 0.0, omga = 1.0, asya = 0.0;
-    if (d.tauaer) {
-      const long o = ((long)b * L + l) * N + col;
-      taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o];
-    }
-    // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
-    double ztauc = taur + taug + taua;
-    double zomcc = taur * 1.0 + taua * omga;
-    double zgcc = asya * omga * taua / zomcc;
-    zomcc = zomcc / ztauc;
+    SwLayerOpt oc, ot;
+    sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
     {
-      const double zf = zgcc * zgcc, zwf = zomcc * zf;
-      ztauc = (1.0 - zwf) * ztauc;
-      zomcc = (zomcc - zwf) / (1.0 - zwf);
-      zgcc = (zgcc - zf) / (1.0 - zf);
-    }
-    double refc, refdc, trac, tradc;
-    sw_reftra(exp_tbl, zgcc, prmu0, ztauc, zomcc, refc, refdc, trac, tradc);
-    const double dbtc = sw_dbt(exp_tbl, ztauc, prmu0);
-    {
-      const double zr = 1.0 / (1.0 - rupdc * refdc);
-      const double nrup = refc + (tradc * ((trac - dbtc) * rupdc + dbtc * rupc)) * zr;
-      const double nrupd = refdc + tradc * tradc * rupdc * zr;
+      const double zr = 1.0 / (1.0 - rupdc * oc.refd);
+      const double nrup = oc.ref + (oc.trad * ((oc.tra - oc.dbt) * rupdc + oc.dbt * rupc)) * zr;
+      const double nrupd = oc.refd + oc.trad * oc.trad * rupdc * zr;
       rupc = nrup; rupdc = nrupd;
     }
-    S(F_REF, l) = refc; S(F_REFD, l) = refdc; S(F_TRA, l) = trac; S(F_TRAD, l) = tradc;
-    S(F_DBT, l) = dbtc; S(F_RUP, l) = rupc; S(F_RUPD, l) = rupdc;
-    if (cloudy_col) {
-      double ref = refc, refd = refdc, tra = trac, trad = tradc, dbt = dbtc;
-      bool lcld;
-      double zcloud;
-      if (d.mcica) { lcld = (mw[l >> 6] >> (l & 63)) & 1ull; zcloud = lcld ? 1.0 : 0.0; }
-      else { zcloud = d.cldfr[i]; lcld = zcloud > 1.e-12; }
-      const long o = ((long)b * L + l) * N + col;
-      const double ptauc = (lcld || !d.mcica) ? d.ctau[o] : 0.0;
-      if (lcld) {
-        const double pomgc = d.cssa[o], pasyc = d.casm[o];
-        // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
-        const double ztauo = ztauc + ptauc;
-        double zomco = ztauc * zomcc + ptauc * pomgc;
-        const double zgco = (ptauc * pomgc * pasyc + ztauc * zomcc * zgcc) / zomco;
-        zomco = zomco / ztauo;
-        double refo, refdo, trao, trado;
-        sw_reftra(exp_tbl, zgco, prmu0, ztauo, zomco, refo, refdo, trao, trado);
-        const double dbto = sw_dbt(exp_tbl, ztauo, prmu0);
-        if (d.mcica) {
-          ref = refo; refd = refdo; tra = trao; trad = trado; dbt = dbto;
-        } else {
-          const double zclear = 1.0 - zcloud;
-          ref = zclear * refc + zcloud * refo; refd = zclear * refdc + zcloud * refdo;
-          tra = zclear * trac + zcloud * trao; trad = zclear * tradc + zcloud * trado;
-          dbt = zclear * dbtc + zcloud * dbto;
-        }
-      } else if (!d.mcica && zcloud != 0.0) {
-        // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
-        const double zclear = 1.0 - zcloud;
-        const double dbto = sw_dbt(exp_tbl, ztauc + ptauc, prmu0);
-        ref = zclear * refc; refd = zclear * refdc; tra = zclear * trac + zcloud; trad = zclear * tradc + zcloud;
-        dbt = zclear * dbtc + zcloud * dbto;
-      }
-      const double zr = 1.0 / (1.0 - rupd * refd);
-      const double nrup = ref + (trad * ((tra - dbt) * rupd + dbt * rup)) * zr;
-      const double nrupd = refd + trad * trad * rupd * zr;
+    S(F_RUP, l) = rupc; S(F_RUPD, l) = rupdc;
+    if (c.cloudy_col) {
+      const double zr = 1.0 / (1.0 - rupd * ot.refd);
+      const double nrup = ot.ref + (ot.trad * ((ot.tra - ot.dbt) * rupd + ot.dbt * rup)) * zr;
+      const double nrupd = ot.refd + ot.trad * ot.trad * rupd * zr;
       rup = nrup; rupd = nrupd;
-      S(F_NCLR + F_REF, l) = ref; S(F_NCLR + F_REFD, l) = refd; S(F_NCLR + F_TRA, l) = tra; S(F_NCLR + F_TRAD, l) = trad;
-      S(F_NCLR + F_DBT, l) = dbt; S(F_NCLR + F_RUP, l) = rup; S(F_NCLR + F_RUPD, l) = rupd;
+      S(F_NCLR + F_RUP, l) = rup; S(F_NCLR + F_RUPD, l) = rupd;
     }
   }
 
-  // ---- sweep 2: top -> bottom; fluxes at every interface -------------------------------------
-  double *pfu = d.part + (((long)iw * 4 + 0) * (L + 1)) * N + col;
-  double *pfd = d.part + (((long)iw * 4 + 1) * (L + 1)) * N + col;
-  double *pcu = d.part + (((long)iw * 4 + 2) * (L + 1)) * N + col;
-  double *pcd = d.part + (((long)iw * 4 + 3) * (L + 1)) * N + col;
+  // ---- sweep 2: top -> bottom; downward recurrence + fluxes at every interface (:142-169) -------------
   double tdnc = 1.0, rdndc = 0.0, tdbtc = 1.0, tdn = 1.0, rdnd = 0.0, tdbt = 1.0;
   for (int lev = L; lev >= 0; --lev) {
     const double rc = (lev > 0) ? S(F_RUP, lev - 1) : albp;
@@ -781,36 +817,30 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
     double zr = 1.0 / (1.0 - rdndc * rdc);
     const double cu = (tdbtc * rc + (tdnc - tdbtc) * rdc) * zr;
     const double cd = tdbtc + (tdnc - tdbtc + tdbtc * rc * rdndc) * zr;
-    pcu[(long)lev * N] = zinc * cu;
-    pcd[(long)lev * N] = zinc * cd;
-    if (cloudy_col) {
+    double fu = cu, fd = cd;
+    if (c.cloudy_col) {
       const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1) : albp;
       const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1) : albd;
       zr = 1.0 / (1.0 - rdnd * rd);
-      const double fu = (tdbt * r + (tdn - tdbt) * rd) * zr;
-      const double fd = tdbt + (tdn - tdbt + tdbt * r * rdnd) * zr;
-      pfu[(long)lev * N] = zinc * fu;
-      pfd[(long)lev * N] = zinc * fd;
-    } else {
-      pfu[(long)lev * N] = zinc * cu;
-      pfd[(long)lev * N] = zinc * cd;
+      fu = (tdbt * r + (tdn - tdbt) * rd) * zr;
+      fd = tdbt + (tdn - tdbt + tdbt * r * rdnd) * zr;
     }
+    sink.emit(lev, zinc * fu, zinc * fd, zinc * cu, zinc * cd);
     if (lev > 0) {
       const int l = lev - 1;
+      SwLayerOpt oc, ot;
+      sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
       {
-        const double ref = S(F_REF, l), refd = S(F_REFD, l), tra = S(F_TRA, l), trad = S(F_TRAD, l), dbt = S(F_DBT, l);
-        zr = 1.0 / (1.0 - refd * rdndc);
-        const double ntdn = tdbtc * tra + (trad * ((tdnc - tdbtc) + tdbtc * ref * rdndc)) * zr;
-        const double nrdnd = refd + trad * trad * rdndc * zr;
-        tdnc = ntdn; rdndc = nrdnd; tdbtc = dbt * tdbtc;
+        zr = 1.0 / (1.0 - oc.refd * rdndc);
+        const double ntdn = tdbtc * oc.tra + (oc.trad * ((tdnc - tdbtc) + tdbtc * oc.ref * rdndc)) * zr;
+        const double nrdnd = oc.refd + oc.trad * oc.trad * rdndc * zr;
+        tdnc = ntdn; rdndc = nrdnd; tdbtc = oc.dbt * tdbtc;
       }
-      if (cloudy_col) {
-        const double ref = S(F_NCLR + F_REF, l), refd = S(F_NCLR + F_REFD, l), tra = S(F_NCLR + F_TRA, l),
-                     trad = S(F_NCLR + F_TRAD, l), dbt = S(F_NCLR + F_DBT, l);
-        zr = 1.0 / (1.0 - refd * rdnd);
-        const double ntdn = tdbt * tra + (trad * ((tdn - tdbt) + tdbt * ref * rdnd)) * zr;
-        const double nrdnd = refd + trad * trad * rdnd * zr;
-        tdn = ntdn; rdnd = nrdnd; tdbt = dbt * tdbt;
+      if (c.cloudy_col) {
+        zr = 1.0 / (1.0 - ot.refd * rdnd);
+        const double ntdn = tdbt * ot.tra + (ot.trad * ((tdn - tdbt) + tdbt * ot.ref * rdnd)) * zr;
+        const double nrdnd = ot.refd + ot.trad * ot.trad * rdnd * zr;
+        tdn = ntdn; rdnd = nrdnd; tdbt = ot.dbt * tdbt;
       }
     }
   }
@@ -819,11 +849,12 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
 // one thread per (column, interface level): g-point sum in reference order
-RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev) {
+// nparts = 112 (per-g-point partials, host emulation) or 28 (block-reduced partials of the device kernel)
+RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev, int nparts) {
   const int L = d.nlay, N = d.ncol;
   double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
   const long st = (long)(L + 1) * N;
-  for (int iw = 0; iw < kSwNGpt; ++iw) {
+  for (int iw = 0; iw < nparts; ++iw) {
     const double *p = d.part + ((long)iw * 4 * (L + 1) + lev) * N + col;
     fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
   }

@@ -20,7 +20,10 @@ static void emu_lw_solve(const LwDev &d, const LwTab &T) {
   const int ng = T.b[BAND - 1].ng;
   std::vector<double> scr((size_t)LF_N * d.nlay);
   for (int ig = 0; ig < ng; ++ig)
-    for (int col = 0; col < d.ncol; ++col) lw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1);
+    for (int col = 0; col < d.ncol; ++col) {
+      LwPartSink sink = lw_part_sink(d, T.b[BAND - 1].gs + ig, col);
+      lw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1, sink);
+    }
 }
 
 extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, double cpdair, const double *consts, char *errbuf, int errlen) {
@@ -92,7 +95,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   emu_lw_solve<1>(d, T); emu_lw_solve<2>(d, T); emu_lw_solve<3>(d, T); emu_lw_solve<4>(d, T); emu_lw_solve<5>(d, T); emu_lw_solve<6>(d, T);
   emu_lw_solve<7>(d, T); emu_lw_solve<8>(d, T); emu_lw_solve<9>(d, T); emu_lw_solve<10>(d, T); emu_lw_solve<11>(d, T); emu_lw_solve<12>(d, T);
   emu_lw_solve<13>(d, T); emu_lw_solve<14>(d, T); emu_lw_solve<15>(d, T); emu_lw_solve<16>(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev, kLwNGpt);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;

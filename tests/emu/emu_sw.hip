@@ -25,7 +25,10 @@ static void emu_solve(const SwDev &d, const SwTab &T) {
   const int ng = T.b[BAND - 16].ng;
   std::vector<double> scr((size_t)F_NTOT * d.nlay);
   for (int ig = 0; ig < ng; ++ig)
-    for (int col = 0; col < d.ncol; ++col) sw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1);
+    for (int col = 0; col < d.ncol; ++col) {
+      SwPartSink sink = sw_part_sink(d, T.b[BAND - 16].gs + ig, col);
+      sw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1, sink);
+    }
 }
 
 extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, double cpdair, const double *consts, char *errbuf, int errlen) {
@@ -110,7 +113,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   emu_solve<16>(d, T); emu_solve<17>(d, T); emu_solve<18>(d, T); emu_solve<19>(d, T); emu_solve<20>(d, T);
   emu_solve<21>(d, T); emu_solve<22>(d, T); emu_solve<23>(d, T); emu_solve<24>(d, T); emu_solve<25>(d, T);
   emu_solve<26>(d, T); emu_solve<27>(d, T); emu_solve<28>(d, T); emu_solve<29>(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, kSwNGpt);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) sw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
