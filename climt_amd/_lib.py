@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "_lib", "librrtmg_hip.so")
+LIB_PATH = os.environ.get("RRTMG_HIP_LIB") or os.path.join(HERE, "_lib", "librrtmg_hip.so")
 SW_DATA = os.path.join(HERE, "data", "rrtmg_sw_data.bin")
 LW_DATA = os.path.join(HERE, "data", "rrtmg_lw_data.bin")
 

@@ -19,11 +19,13 @@ def build(force=False, verbose=True):
     if not force and os.path.exists(OUT) and os.path.getmtime(OUT) >= _newest(deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", OUT] + srcs
+    out = os.environ.get("RRTMG_HIP_BUILD_OUT", OUT)   # A/B builds: RRTMG_HIP_BUILD_FLAGS="-DRRTMG_EXACT_DIV"
+    extra = os.environ.get("RRTMG_HIP_BUILD_FLAGS", "").split()
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + extra + ["-o", out] + srcs
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return OUT
+    return out
 
 
 if __name__ == "__main__":

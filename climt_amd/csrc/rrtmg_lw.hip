@@ -66,13 +66,14 @@ struct LwBlockSink {
   }
 };
 
-__global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8) {
+__global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8, int tile_order) {
   __shared__ double sh[2][kLwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
   const int ngrp = kLwNGpt / kLwGroup;
-  const int grp = r % ngrp, tile = (r / ngrp) * 8 + xcd;
-  (void)ntile8;
+  const int nt = ntile8 >> 3;   // tiles per XCD
+  const int grp = tile_order ? r / nt : r % ngrp;
+  const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
   const int iw = grp * kLwGroup + threadIdx.y;
@@ -192,16 +193,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (!ok) return ctx->status;
 
   auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("lw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
-  d.fac00 = wd("fac00", nl); d.fac01 = wd("fac01", nl); d.fac10 = wd("fac10", nl); d.fac11 = wd("fac11", nl);
-  d.selffac = wd("selffac", nl); d.selffrac = wd("selffrac", nl); d.forfac = wd("forfac", nl); d.forfrac = wd("forfrac", nl);
-  d.minorfrac = wd("minorfrac", nl); d.scaleminor = wd("scaleminor", nl); d.scaleminorn2 = wd("scaleminorn2", nl);
-  d.colh2o = wd("colh2o", nl); d.colco2 = wd("colco2", nl); d.colo3 = wd("colo3", nl); d.coln2o = wd("coln2o", nl);
-  d.colco = wd("colco", nl); d.colch4 = wd("colch4", nl); d.colo2 = wd("colo2", nl); d.colbrd = wd("colbrd", nl); d.coldry = wd("coldry", nl);
-  d.wx1 = wd("wx1", nl); d.wx2 = wd("wx2", nl); d.wx3 = wd("wx3", nl); d.wx4 = wd("wx4", nl);
+  d.prep = wd("prep", lw_prep_size(N, L));
   d.secdiff = wd("secdiff", (size_t)N * 16);
-  d.idx = (int32_t *)ctx->buf("lw.w.idx", nl * 4); d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
+  d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
   d.ncbands = (int32_t *)ctx->buf("lw.w.ncbands", (size_t)N * 4);
-  if (!d.idx || !d.laytrop || !d.ncbands) ok = false;
+  if (!d.laytrop || !d.ncbands) ok = false;
   if (clouds) d.ctau = wd("ctau", nl * 16);
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) {
@@ -255,7 +251,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   {
     const int ntile8 = (ntile + 7) / 8 * 8;
     (void)hipEventRecord(ctx->ev[1][0], s);
-    hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile8 * (kLwNGpt / kLwGroup)), dim3(64, kLwGroup), 0, s, d, T, ntile8);
+    hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile8 * (kLwNGpt / kLwGroup)), dim3(64, kLwGroup), 0, s, d, T, ntile8, ctx->tile_order);
     (void)hipEventRecord(ctx->ev[1][1], s);
     ctx->ev_valid[1] = true;
   }

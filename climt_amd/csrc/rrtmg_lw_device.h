@@ -6,7 +6,7 @@
 //   lw_cloud_column  one thread per column : cldprop (non-McICA; the reference's layer-order dependent
 //                    ncbands bookkeeping is reproduced)   /  lw_cloudmc_layer: cldprmc band optics
 //   lw_solve_thread  one thread per (column, g-point): downward sweep (taumol for the layer, Planck
-//                    terms, no-scattering recurrence; layer state spilled to a [field][layer][lane]
+//                    terms, no-scattering recurrence; layer state spilled to a [layer][field][lane]
 //                    scratch slab), surface reflection, upward sweep.
 //   lw_flux_level / lw_heat_layer  band / g-point integration, flux scaling; heating rates.
 //
@@ -49,12 +49,9 @@ struct LwDev {
   const double *play, *plev, *tlay, *tlev, *tsfc, *h2o, *o3, *co2, *ch4, *n2o, *o2;
   const double *cfc11, *cfc12, *cfc22, *ccl4, *emis;
   const double *cldfr, *taucld, *cicewp, *cliqwp, *reice, *reliq, *tauaer;
-  // prep products [lay][col]
-  double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac, *minorfrac;
-  double *scaleminor, *scaleminorn2;
-  double *colh2o, *colco2, *colo3, *coln2o, *colco, *colch4, *colo2, *colbrd, *coldry;
-  double *wx1, *wx2, *wx3, *wx4;
-  int32_t *idx;        // jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<20 | indminor<<24
+  // prep products: ONE slab [tile][layer][LP_N fields][64 lanes] -- a wavefront reads the rows of its
+  // (tile, layer) at constant offsets from a single address (lw_prep_off), see enum LwPrepField
+  double *prep;
   int32_t *laytrop;    // [col]
   double *secdiff;     // [16][col]
   // clouds
@@ -68,6 +65,17 @@ struct LwDev {
   int *err;
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
 };
+
+// rows of the prep slab; LP_IDX holds jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<20 | indminor<<24 as an
+// (exact) double, LP_PAVEL a copy of the layer pressure
+enum LwPrepField { LP_FAC00 = 0, LP_FAC01, LP_FAC10, LP_FAC11, LP_SELFFAC, LP_SELFFRAC, LP_FORFAC, LP_FORFRAC,
+                   LP_MINORFRAC, LP_SCALEMINOR, LP_SCALEMINORN2, LP_COLH2O, LP_COLCO2, LP_COLO3, LP_COLN2O,
+                   LP_COLCO, LP_COLCH4, LP_COLO2, LP_COLBRD, LP_COLDRY, LP_WX1, LP_WX2, LP_WX3, LP_WX4, LP_PAVEL,
+                   LP_IDX, LP_N };
+RRTMG_HD long lw_prep_off(int nlay, int col, int lay) {
+  return ((long)(col >> 6) * nlay + lay) * (LP_N * 64) + (col & 63);
+}
+RRTMG_HD size_t lw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) / 64) * nlay * LP_N * 64; }
 
 // ------------------------------------------------------------------------------------------
 // inatm (rrtmg_lw_rad.nomcica.f90:744-880) + setcoef indices (rrtmg_lw_setcoef.f90:253-411)
@@ -93,10 +101,11 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
     const double w1 = coldry * v1, w2 = coldry * v2, w3 = coldry * v3, w4 = coldry * v4, w5 = coldry * 0.0, w6 = coldry * v6, w7 = coldry * v7;
     amttl = amttl + coldry + w1;
     wvttl = wvttl + w1;
-    d.wx1[i] = coldry * (d.ccl4 ? d.ccl4[i] : 0.0) * 1.e-20;
-    d.wx2[i] = coldry * (d.cfc11 ? d.cfc11[i] : 0.0) * 1.e-20;
-    d.wx3[i] = coldry * (d.cfc12 ? d.cfc12[i] : 0.0) * 1.e-20;
-    d.wx4[i] = coldry * (d.cfc22 ? d.cfc22[i] : 0.0) * 1.e-20;
+    double *q = d.prep + lw_prep_off(L, col, l);
+    q[LP_WX1 * 64] = coldry * (d.ccl4 ? d.ccl4[i] : 0.0) * 1.e-20;
+    q[LP_WX2 * 64] = coldry * (d.cfc11 ? d.cfc11[i] : 0.0) * 1.e-20;
+    q[LP_WX3 * 64] = coldry * (d.cfc12 ? d.cfc12[i] : 0.0) * 1.e-20;
+    q[LP_WX4 * 64] = coldry * (d.cfc22 ? d.cfc22[i] : 0.0) * 1.e-20;
 
     const double plog = log(pavel);
     int jp = (int)(36.0 - 5 * (plog + 0.04));
@@ -146,16 +155,17 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
     if (colch4 == 0.0) colch4 = 1.e-32 * coldry;
     const double colbrd = 1.e-20 * wbroad;
     const double compfp = 1. - fp;
-    d.fac10[i] = compfp * ft;
-    d.fac00[i] = compfp * (1.0 - ft);
-    d.fac11[i] = fp * ft1;
-    d.fac01[i] = fp * (1.0 - ft1);
-    d.selffac[i] = colh2o * selffac; d.forfac[i] = colh2o * forfac;
-    d.selffrac[i] = selffrac; d.forfrac[i] = forfrac; d.minorfrac[i] = minorfrac;
-    d.scaleminor[i] = scaleminor; d.scaleminorn2[i] = scaleminorn2;
-    d.colh2o[i] = colh2o; d.colco2[i] = colco2; d.colo3[i] = colo3; d.coln2o[i] = coln2o; d.colco[i] = colco;
-    d.colch4[i] = colch4; d.colo2[i] = colo2; d.colbrd[i] = colbrd; d.coldry[i] = coldry;
-    d.idx[i] = jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24);
+    q[LP_FAC10 * 64] = compfp * ft;
+    q[LP_FAC00 * 64] = compfp * (1.0 - ft);
+    q[LP_FAC11 * 64] = fp * ft1;
+    q[LP_FAC01 * 64] = fp * (1.0 - ft1);
+    q[LP_SELFFAC * 64] = colh2o * selffac; q[LP_FORFAC * 64] = colh2o * forfac;
+    q[LP_SELFFRAC * 64] = selffrac; q[LP_FORFRAC * 64] = forfrac; q[LP_MINORFRAC * 64] = minorfrac;
+    q[LP_SCALEMINOR * 64] = scaleminor; q[LP_SCALEMINORN2 * 64] = scaleminorn2;
+    q[LP_COLH2O * 64] = colh2o; q[LP_COLCO2 * 64] = colco2; q[LP_COLO3 * 64] = colo3; q[LP_COLN2O * 64] = coln2o;
+    q[LP_COLCO * 64] = colco; q[LP_COLCH4 * 64] = colch4; q[LP_COLO2 * 64] = colo2; q[LP_COLBRD * 64] = colbrd;
+    q[LP_COLDRY * 64] = coldry; q[LP_PAVEL * 64] = pavel;
+    q[LP_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24));
   }
   d.laytrop[col] = laytrop;
   const double wvsh = (amw * wvttl) / (amd * amttl);
@@ -352,14 +362,16 @@ struct LwLayerIn {
   int jp, jt, jt1, indself, indfor, indminor;
 };
 
-RRTMG_HD void lw_load_layer(const LwDev &d, long i, LwLayerIn &s) {
-  s.fac00 = d.fac00[i]; s.fac01 = d.fac01[i]; s.fac10 = d.fac10[i]; s.fac11 = d.fac11[i];
-  s.selffac = d.selffac[i]; s.selffrac = d.selffrac[i]; s.forfac = d.forfac[i]; s.forfrac = d.forfrac[i];
-  s.minorfrac = d.minorfrac[i]; s.scaleminor = d.scaleminor[i]; s.scaleminorn2 = d.scaleminorn2[i];
-  s.colh2o = d.colh2o[i]; s.colco2 = d.colco2[i]; s.colo3 = d.colo3[i]; s.coln2o = d.coln2o[i]; s.colco = d.colco[i];
-  s.colch4 = d.colch4[i]; s.colo2 = d.colo2[i]; s.colbrd = d.colbrd[i]; s.coldry = d.coldry[i]; s.pavel = d.play[i];
-  s.wx1 = d.wx1[i]; s.wx2 = d.wx2[i]; s.wx3 = d.wx3[i]; s.wx4 = d.wx4[i];
-  const int p = d.idx[i];
+RRTMG_HD void lw_load_layer(const LwDev &d, int col, int lay, LwLayerIn &s) {
+  const double *q = d.prep + lw_prep_off(d.nlay, col, lay);
+  s.fac00 = q[LP_FAC00 * 64]; s.fac01 = q[LP_FAC01 * 64]; s.fac10 = q[LP_FAC10 * 64]; s.fac11 = q[LP_FAC11 * 64];
+  s.selffac = q[LP_SELFFAC * 64]; s.selffrac = q[LP_SELFFRAC * 64]; s.forfac = q[LP_FORFAC * 64]; s.forfrac = q[LP_FORFRAC * 64];
+  s.minorfrac = q[LP_MINORFRAC * 64]; s.scaleminor = q[LP_SCALEMINOR * 64]; s.scaleminorn2 = q[LP_SCALEMINORN2 * 64];
+  s.colh2o = q[LP_COLH2O * 64]; s.colco2 = q[LP_COLCO2 * 64]; s.colo3 = q[LP_COLO3 * 64]; s.coln2o = q[LP_COLN2O * 64];
+  s.colco = q[LP_COLCO * 64]; s.colch4 = q[LP_COLCH4 * 64]; s.colo2 = q[LP_COLO2 * 64]; s.colbrd = q[LP_COLBRD * 64];
+  s.coldry = q[LP_COLDRY * 64]; s.pavel = q[LP_PAVEL * 64];
+  s.wx1 = q[LP_WX1 * 64]; s.wx2 = q[LP_WX2 * 64]; s.wx3 = q[LP_WX3 * 64]; s.wx4 = q[LP_WX4 * 64];
+  const int p = (int)q[LP_IDX * 64];
   s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xf; s.indfor = (p >> 20) & 0xf;
   s.indminor = (p >> 24) & 0x1f;
 }
@@ -724,7 +736,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
   const double secd = d.secdiff[(long)ib * N + col];
   const double wtdiff = 0.5, delw = t[T.delwave + ib];
   (void)iw;
-  auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
+  auto S = [&](int f, int l) -> double & { return scr[((long)l * LF_N + f) * stride]; };
   auto W = [&](double r) { return (r * wtdiff) * delw; };
 
   // cloud bookkeeping
@@ -734,7 +746,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
   double secd_cb = secd;
   if (clouds) {
     if (d.mcica) {
-      for (int w = 0; w < d.nw && w < 4; ++w) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; aw[w] = d.anymask[(long)w * N + col]; }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) if (w < d.nw) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; aw[w] = d.anymask[(long)w * N + col]; }
     } else {
       const int ncb = d.ncbands[col];
       const int ipat1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
@@ -753,7 +766,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
     const int l = lev - 1;
     const long i = (long)l * N + col;
     LwLayerIn s;
-    lw_load_layer(d, i, s);
+    lw_load_layer(d, col, l, s);
     double plfrac;
     const double taug = lw_taug<BAND>(T, s, lev <= laytrop, ig, plfrac);
     const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;

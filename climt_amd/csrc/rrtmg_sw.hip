@@ -78,13 +78,14 @@ struct SwBlockSink {
   }
 };
 
-__global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8) {
+__global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8, int tile_order) {
   __shared__ double sh[2][kSwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
   const int ngrp = kSwNGpt / kSwGroup;
-  const int grp = r % ngrp, tile = (r / ngrp) * 8 + xcd;
-  (void)ntile8;
+  const int nt = ntile8 >> 3;   // tiles per XCD
+  const int grp = tile_order ? r / nt : r % ngrp;
+  const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
   const int iw = grp * kSwGroup + threadIdx.y;
@@ -252,13 +253,11 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 
   // ---- work buffers -------------------------------------------------------------------------
   auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("sw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
-  d.fac00 = wd("fac00", nl); d.fac01 = wd("fac01", nl); d.fac10 = wd("fac10", nl); d.fac11 = wd("fac11", nl);
-  d.selffac = wd("selffac", nl); d.selffrac = wd("selffrac", nl); d.forfac = wd("forfac", nl); d.forfrac = wd("forfrac", nl);
-  d.colh2o = wd("colh2o", nl); d.colco2 = wd("colco2", nl); d.colo3 = wd("colo3", nl); d.colch4 = wd("colch4", nl);
-  d.colo2 = wd("colo2", nl); d.colmol = wd("colmol", nl); d.pdp = wd("pdp", nl); d.cossza = wd("cossza", N);
-  d.idx = (int32_t *)ctx->buf("sw.w.idx", nl * 4); d.laytrop = (int32_t *)ctx->buf("sw.w.laytrop", (size_t)N * 4);
+  d.prep = wd("prep", sw_prep_size(N, L));
+  d.pdp = wd("pdp", nl); d.cossza = wd("cossza", N);
+  d.laytrop = (int32_t *)ctx->buf("sw.w.laytrop", (size_t)N * 4);
   d.laysolfr = (int32_t *)ctx->buf("sw.w.laysolfr", (size_t)N * 4 * kSwNBand); d.anycld = (int32_t *)ctx->buf("sw.w.anycld", (size_t)N * 4);
-  if (!d.idx || !d.laytrop || !d.laysolfr || !d.anycld) ok = false;
+  if (!d.laytrop || !d.laysolfr || !d.anycld) ok = false;
   if (clouds) { d.ctau = wd("ctau", nl * kSwNBand); d.cssa = wd("cssa", nl * kSwNBand); d.casm = wd("casm", nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
@@ -307,7 +306,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   {
     const int ntile8 = (ntile + 7) / 8 * 8;
     (void)hipEventRecord(ctx->ev[0][0], s);
-    hipLaunchKernelGGL(sw_solve_all_kernel, dim3(ntile8 * (kSwNGpt / kSwGroup)), dim3(64, kSwGroup), 0, s, d, T, ntile8);
+    hipLaunchKernelGGL(sw_solve_all_kernel, dim3(ntile8 * (kSwNGpt / kSwGroup)), dim3(64, kSwGroup), 0, s, d, T, ntile8, ctx->tile_order);
     (void)hipEventRecord(ctx->ev[0][1], s);
     ctx->ev_valid[0] = true;
   }

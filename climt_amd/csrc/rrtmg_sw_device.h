@@ -9,7 +9,7 @@
 //                    coalesced 512-B row of the [layer][column] arrays, and k-table gathers of a
 //                    wave fall in one contiguous [g][index] slice.  Two sweeps over the layers:
 //                    up (taumol + delta scaling + reftra + upward adding recurrence, level state
-//                    spilled to a [field][layer][lane] scratch slab) and down (downward adding
+//                    spilled to a [layer][field][lane] scratch slab) and down (downward adding
 //                    recurrence + flux assembly).
 //   sw_flux_level / sw_heat_layer  spectral integration in g-point order; heating rates.
 //
@@ -59,10 +59,9 @@ struct SwDev {
   const double *asdir, *asdif, *aldir, *aldif, *coszen;
   const double *cldfr, *taucld, *ssacld, *asmcld, *fsfcld, *cicewp, *cliqwp, *reice, *reliq;
   const double *tauaer, *ssaaer, *asmaer;   // effective per-band aerosol [14][lay][col] or null
-  // prep products
-  double *fac00, *fac01, *fac10, *fac11, *selffac, *selffrac, *forfac, *forfrac;
-  double *colh2o, *colco2, *colo3, *colch4, *colo2, *colmol;
-  int32_t *idx;        // jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<24
+  // prep products: ONE slab [tile][layer][SP_N fields][64 lanes] -- a wavefront reads the SP_N rows of its
+  // (tile, layer) at constant offsets from a single address (sw_prep_off), see enum SwPrepField
+  double *prep;
   int32_t *laytrop;    // [col]
   int32_t *laysolfr;   // [14][col], 1-based layer, 0 = source never set
   int32_t *anycld;     // [col] nomcica: 1 if any layer has cldfr > 0
@@ -71,7 +70,7 @@ struct SwDev {
   double *ctau, *cssa, *casm;   // delta-scaled cloud optics [14][lay][col]
   uint64_t *mask;      // McICA cloud mask bits [112][nw][col]
   int nw;
-  double *scratch;     // per band launch: [block][field][lay][64]
+  double *scratch;     // [tile][g-point][lay][field][64]
   double *part;        // [112][4][nlay+1][col]  weighted (fu, fd, cu, cd)
   int *err;
   // outputs
@@ -79,6 +78,14 @@ struct SwDev {
 };
 
 enum { SP_H2O = 0, SP_CO2 = 1, SP_O3 = 2, SP_CH4 = 3, SP_O2 = 4 };
+
+// rows of the prep slab; P_IDX holds jp | jt<<8 | jt1<<12 | indself<<16 | indfor<<24 as an (exact) double
+enum SwPrepField { P_FAC00 = 0, P_FAC01, P_FAC10, P_FAC11, P_SELFFAC, P_SELFFRAC, P_FORFAC, P_FORFRAC,
+                   P_COLH2O, P_COLCO2, P_COLO3, P_COLCH4, P_COLO2, P_COLMOL, P_IDX, SP_N };
+RRTMG_HD long sw_prep_off(int nlay, int col, int lay) {
+  return ((long)(col >> 6) * nlay + lay) * (SP_N * 64) + (col & 63);
+}
+RRTMG_HD size_t sw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) / 64) * nlay * SP_N * 64; }
 
 // ------------------------------------------------------------------------------------------
 // inatm_sw (rrtmg_sw_rad.nomcica.f90:1441-1465) + setcoef_sw (rrtmg_sw_setcoef.f90:137-303)
@@ -144,14 +151,15 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
     if (colch4 == 0.0) colch4 = 1.e-32 * coldry;
     if (colo2 == 0.0) colo2 = 1.e-32 * coldry;
     const double compfp = 1.0 - fp;
-    d.fac10[i] = compfp * ft;
-    d.fac00[i] = compfp * (1.0 - ft);
-    d.fac11[i] = fp * ft1;
-    d.fac01[i] = fp * (1.0 - ft1);
-    d.selffac[i] = selffac; d.selffrac[i] = selffrac; d.forfac[i] = forfac; d.forfrac[i] = forfrac;
-    d.colh2o[i] = colh2o; d.colco2[i] = colco2; d.colo3[i] = colo3; d.colch4[i] = colch4;
-    d.colo2[i] = colo2; d.colmol[i] = colmol;
-    d.idx[i] = jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24);
+    double *q = d.prep + sw_prep_off(L, col, l);
+    q[P_FAC10 * 64] = compfp * ft;
+    q[P_FAC00 * 64] = compfp * (1.0 - ft);
+    q[P_FAC11 * 64] = fp * ft1;
+    q[P_FAC01 * 64] = fp * (1.0 - ft1);
+    q[P_SELFFAC * 64] = selffac; q[P_SELFFRAC * 64] = selffrac; q[P_FORFAC * 64] = forfac; q[P_FORFRAC * 64] = forfrac;
+    q[P_COLH2O * 64] = colh2o; q[P_COLCO2 * 64] = colco2; q[P_COLO3 * 64] = colo3; q[P_COLCH4 * 64] = colch4;
+    q[P_COLO2 * 64] = colo2; q[P_COLMOL * 64] = colmol;
+    q[P_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24));
     if (d.icld >= 1 && d.cldfr) {
       const double cf = d.cldfr[i];
       if (cf > 0.0) anycld = 1;
@@ -170,13 +178,14 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
   // reference loops, result = last layer for which (lay == laysolfr) held.
   const int layreffr[kSwNBand] = {18, 30, 6, 3, 3, 8, 2, 6, 1, 2, 0, 32, 58, 49};
   const bool upper[kSwNBand] = {true, true, false, false, false, false, false, false, false, false, false, true, true, true};
+  auto jp_of = [&](int lay0) { return (int)d.prep[sw_prep_off(L, col, lay0) + P_IDX * 64] & 0xff; };
   for (int b = 0; b < kSwNBand; ++b) {
     int fin = 0;
     if (upper[b]) {
       int ls = L;
       for (int lay = laytrop + 1; lay <= L; ++lay) {
-        const int jpm = (lay >= 2) ? (d.idx[(long)(lay - 2) * N + col] & 0xff) : 0;
-        const int jpc = d.idx[(long)(lay - 1) * N + col] & 0xff;
+        const int jpm = (lay >= 2) ? jp_of(lay - 2) : 0;
+        const int jpc = jp_of(lay - 1);
         if (jpm < layreffr[b] && jpc >= layreffr[b]) ls = lay;
         if (lay == ls) fin = lay;
       }
@@ -184,8 +193,8 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
       int ls = laytrop;
       for (int lay = 1; lay <= laytrop; ++lay) {
         if (b != 10) {  // band 26 has no layreffr test
-          const int jpc = d.idx[(long)(lay - 1) * N + col] & 0xff;
-          const int jpn = (lay < L) ? (d.idx[(long)lay * N + col] & 0xff) : 0;
+          const int jpc = jp_of(lay - 1);
+          const int jpn = (lay < L) ? jp_of(lay) : 0;
           if (jpc < layreffr[b] && jpn >= layreffr[b]) ls = (lay + 1 < laytrop) ? lay + 1 : laytrop;
         }
         if (lay == ls) fin = lay;
@@ -409,8 +418,8 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double z
   const double zgamma2 = 3.0 * (zw * (1.0 - zg)) * 0.25;
   const double zgamma3 = (2.0 - zg3 * prmuz) * 0.25;
   const double zgamma4 = 1.0 - zgamma3;
-  const double zq = zg / (1.0 - zg);
-  const double zwo = zw / (1.0 - (1.0 - zw) * (zq * zq));
+  const double zq = qdiv(zg, 1.0 - zg);
+  const double zwo = qdiv(zw, 1.0 - (1.0 - zw) * (zq * zq));
   if (zwo >= zwcrit) {
     const double za = zgamma1 * prmuz;
     const double za1 = za - zgamma3;
@@ -419,9 +428,9 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double z
     if (ze1 > 500.0) ze1 = 500.0;
     double ze2;
     if (ze1 <= od_lo) ze2 = 1.0 - ze1 + 0.5 * ze1 * ze1; else ze2 = sw_exp_lookup(exp_tbl, ze1);
-    pref = (zgt - za1 * (1.0 - ze2)) / (1.0 + zgt);
+    pref = qdiv(zgt - za1 * (1.0 - ze2), 1.0 + zgt);   // same denominator below: one rcp on the device
     ptra = 1.0 - pref;
-    prefd = zgt / (1.0 + zgt);
+    prefd = qdiv(zgt, 1.0 + zgt);
     ptrad = 1.0 - prefd;
     if (ze2 == 1.0) { pref = 0.0; ptra = 1.0; prefd = 0.0; ptrad = 1.0; }
   } else {
@@ -441,25 +450,24 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double z
     const double zt1 = zrp1 * (za1 + zrk * zgamma4);
     const double zt2 = zrm1 * (za1 - zrk * zgamma4);
     const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-    const double zbeta = (zgamma1 - zrk) / zrkg;
+    const double zbeta = qdiv(zgamma1 - zrk, zrkg);
     double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
     double ze2 = zto1 / prmuz; if (ze2 > 500.0) ze2 = 500.0;
     double zem1, zem2;
     if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
-    const double zep1 = 1.0 / zem1;
+    const double zep1 = qrcp(zem1);
     if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
-    const double zep2 = 1.0 / zem2;
+    const double zep2 = qrcp(zem2);
     const double zdenr = zr4 * zep1 + zr5 * zem1;
-    const double zdent = zr4 * zep1 + zr5 * zem1;   // zt4 = zr4, zt5 = zr5
     if (zdenr >= -eps && zdenr <= eps) {
       pref = eps;
       ptra = zem2;
     } else {
-      pref = zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2) / zdenr;
-      ptra = zem2 - zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2) / zdent;
+      pref = qdiv(zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2), zdenr);
+      ptra = zem2 - qdiv(zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2), zdenr);   // zdent == zdenr
     }
     const double zemm = zem1 * zem1;
-    const double zdend = 1.0 / ((1.0 - zbeta * zemm) * zrkg);
+    const double zdend = qrcp((1.0 - zbeta * zemm) * zrkg);
     prefd = zgamma2 * (1.0 - zemm) * zdend;
     ptrad = zrk2 * zem1 * zdend;
   }
@@ -474,12 +482,13 @@ struct SwLayerIn {
   int jp, jt, jt1, indself, indfor;
 };
 
-RRTMG_HD void sw_load_layer(const SwDev &d, long i, SwLayerIn &s) {
-  s.fac00 = d.fac00[i]; s.fac01 = d.fac01[i]; s.fac10 = d.fac10[i]; s.fac11 = d.fac11[i];
-  s.selffac = d.selffac[i]; s.selffrac = d.selffrac[i]; s.forfac = d.forfac[i]; s.forfrac = d.forfrac[i];
-  s.colh2o = d.colh2o[i]; s.colco2 = d.colco2[i]; s.colo3 = d.colo3[i]; s.colch4 = d.colch4[i];
-  s.colo2 = d.colo2[i]; s.colmol = d.colmol[i];
-  const int p = d.idx[i];
+RRTMG_HD void sw_load_layer(const SwDev &d, int col, int lay, SwLayerIn &s) {
+  const double *q = d.prep + sw_prep_off(d.nlay, col, lay);
+  s.fac00 = q[P_FAC00 * 64]; s.fac01 = q[P_FAC01 * 64]; s.fac10 = q[P_FAC10 * 64]; s.fac11 = q[P_FAC11 * 64];
+  s.selffac = q[P_SELFFAC * 64]; s.selffrac = q[P_SELFFRAC * 64]; s.forfac = q[P_FORFAC * 64]; s.forfrac = q[P_FORFRAC * 64];
+  s.colh2o = q[P_COLH2O * 64]; s.colco2 = q[P_COLCO2 * 64]; s.colo3 = q[P_COLO3 * 64]; s.colch4 = q[P_COLCH4 * 64];
+  s.colo2 = q[P_COLO2 * 64]; s.colmol = q[P_COLMOL * 64];
+  const int p = (int)q[P_IDX * 64];
   s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xff; s.indfor = (p >> 24) & 0xff;
 }
 
@@ -637,9 +646,8 @@ RRTMG_HD double sw_incflux(const SwDev &d, const SwTab &T, int col, int ig, doub
   int js = 1;
   double fs = 0.0;
   if constexpr (C::bin_src) {
-    const long i = (long)(ls - 1) * d.ncol + col;
     SwLayerIn s;
-    sw_load_layer(d, i, s);
+    sw_load_layer(d, col, ls - 1, s);
     const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, C::upper_src ? 4.0 : 8.0);
     js = sp.js; fs = sp.fs;
   }
@@ -705,7 +713,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx 
   const double prmu0 = c.prmu0;
   const long i = (long)l * N + col;
   SwLayerIn s;
-  sw_load_layer(d, i, s);
+  sw_load_layer(d, col, l, s);
   double taur;
   const double taug = sw_taug<BAND>(T, s, (l + 1) <= c.laytrop, c.ig, taur);
   double taua = 0.0, omga = 1.0, asya = 0.0;
@@ -716,13 +724,13 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx 
   // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
   double ztauc = taur + taug + taua;
   double zomcc = taur * 1.0 + taua * omga;
-  double zgcc = asya * omga * taua / zomcc;
-  zomcc = zomcc / ztauc;
+  double zgcc = qdiv(asya * omga * taua, zomcc);
+  zomcc = qdiv(zomcc, ztauc);
   {
     const double zf = zgcc * zgcc, zwf = zomcc * zf;
     ztauc = (1.0 - zwf) * ztauc;
-    zomcc = (zomcc - zwf) / (1.0 - zwf);
-    zgcc = (zgcc - zf) / (1.0 - zf);
+    zomcc = qdiv(zomcc - zwf, 1.0 - zwf);
+    zgcc = qdiv(zgcc - zf, 1.0 - zf);
   }
   sw_reftra(exp_tbl, zgcc, prmu0, ztauc, zomcc, clr.ref, clr.refd, clr.tra, clr.trad);
   clr.dbt = sw_dbt(exp_tbl, ztauc, prmu0);
@@ -739,8 +747,8 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx 
     // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
     const double ztauo = ztauc + ptauc;
     double zomco = ztauc * zomcc + ptauc * pomgc;
-    const double zgco = (ptauc * pomgc * pasyc + ztauc * zomcc * zgcc) / zomco;
-    zomco = zomco / ztauo;
+    const double zgco = qdiv(ptauc * pomgc * pasyc + ztauc * zomcc * zgcc, zomco);
+    zomco = qdiv(zomco, ztauo);
     double refo, refdo, trao, trado;
     sw_reftra(exp_tbl, zgco, prmu0, ztauo, zomco, refo, refdo, trao, trado);
     const double dbto = sw_dbt(exp_tbl, ztauo, prmu0);
@@ -761,7 +769,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx 
   }
 }
 
-// One (column, g-point): both sweeps.  scr -> this thread's element of a [field][layer][stride] slab holding the
+// One (column, g-point): both sweeps.  scr -> this thread's element of a [layer][field][stride] slab holding the
 // upward-sweep results (rup, rupd) for the clear and -- in cloudy columns -- the total sky.
 template <int BAND, class Sink>
 RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, double *scr, long stride, Sink &sink) {
@@ -781,12 +789,14 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
   c.mw[0] = c.mw[1] = c.mw[2] = c.mw[3] = 0;
   if (d.icld >= 1) {
     if (d.mcica) {
-      for (int w = 0; w < d.nw && w < 4; ++w) { c.mw[w] = d.mask[((long)c.iw * d.nw + w) * N + col]; c.cloudy_col |= (c.mw[w] != 0); }
+      // fully unrolled (static indices keep the mask words in registers)
+#pragma unroll
+      for (int w = 0; w < 4; ++w) if (w < d.nw) { c.mw[w] = d.mask[((long)c.iw * d.nw + w) * N + col]; c.cloudy_col |= (c.mw[w] != 0); }
     } else {
       c.cloudy_col = d.anycld[col] != 0;
     }
   }
-  auto S = [&](int f, int l) -> double & { return scr[((long)f * L + l) * stride]; };
+  auto S = [&](int f, int l) -> double & { return scr[((long)l * F_NTOT + f) * stride]; };
 
   // ---- sweep 1: bottom -> top, upward adding recurrence (rrtmg_sw_vrtqdr.f90:114-140) ---------------
   double rupc = albp, rupdc = albd, rup = albp, rupd = albd;
@@ -794,14 +804,14 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
     SwLayerOpt oc, ot;
     sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
     {
-      const double zr = 1.0 / (1.0 - rupdc * oc.refd);
+      const double zr = qrcp(1.0 - rupdc * oc.refd);
       const double nrup = oc.ref + (oc.trad * ((oc.tra - oc.dbt) * rupdc + oc.dbt * rupc)) * zr;
       const double nrupd = oc.refd + oc.trad * oc.trad * rupdc * zr;
       rupc = nrup; rupdc = nrupd;
     }
     S(F_RUP, l) = rupc; S(F_RUPD, l) = rupdc;
     if (c.cloudy_col) {
-      const double zr = 1.0 / (1.0 - rupd * ot.refd);
+      const double zr = qrcp(1.0 - rupd * ot.refd);
       const double nrup = ot.ref + (ot.trad * ((ot.tra - ot.dbt) * rupd + ot.dbt * rup)) * zr;
       const double nrupd = ot.refd + ot.trad * ot.trad * rupd * zr;
       rup = nrup; rupd = nrupd;
@@ -814,14 +824,14 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
   for (int lev = L; lev >= 0; --lev) {
     const double rc = (lev > 0) ? S(F_RUP, lev - 1) : albp;
     const double rdc = (lev > 0) ? S(F_RUPD, lev - 1) : albd;
-    double zr = 1.0 / (1.0 - rdndc * rdc);
+    double zr = qrcp(1.0 - rdndc * rdc);
     const double cu = (tdbtc * rc + (tdnc - tdbtc) * rdc) * zr;
     const double cd = tdbtc + (tdnc - tdbtc + tdbtc * rc * rdndc) * zr;
     double fu = cu, fd = cd;
     if (c.cloudy_col) {
       const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1) : albp;
       const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1) : albd;
-      zr = 1.0 / (1.0 - rdnd * rd);
+      zr = qrcp(1.0 - rdnd * rd);
       fu = (tdbt * r + (tdn - tdbt) * rd) * zr;
       fd = tdbt + (tdn - tdbt + tdbt * r * rdnd) * zr;
     }
@@ -831,13 +841,13 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, d
       SwLayerOpt oc, ot;
       sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
       {
-        zr = 1.0 / (1.0 - oc.refd * rdndc);
+        zr = qrcp(1.0 - oc.refd * rdndc);
         const double ntdn = tdbtc * oc.tra + (oc.trad * ((tdnc - tdbtc) + tdbtc * oc.ref * rdndc)) * zr;
         const double nrdnd = oc.refd + oc.trad * oc.trad * rdndc * zr;
         tdnc = ntdn; rdndc = nrdnd; tdbtc = oc.dbt * tdbtc;
       }
       if (c.cloudy_col) {
-        zr = 1.0 / (1.0 - ot.refd * rdnd);
+        zr = qrcp(1.0 - ot.refd * rdnd);
         const double ntdn = tdbt * ot.tra + (ot.trad * ((tdn - tdbt) + tdbt * ot.ref * rdnd)) * zr;
         const double nrdnd = ot.refd + ot.trad * ot.trad * rdnd * zr;
         tdn = ntdn; rdnd = nrdnd; tdbt = ot.dbt * tdbt;

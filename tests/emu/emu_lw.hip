@@ -56,12 +56,9 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   if (clouds) { d.cldfr = a->cldfr; d.taucld = a->taucld; d.cicewp = a->cicewp; d.cliqwp = a->cliqwp; d.reice = a->reice; d.reliq = a->reliq; }
   std::vector<std::vector<double>> keep;
   auto wd = [&](size_t n) { keep.emplace_back(n, 0.0); return keep.back().data(); };
-  d.fac00 = wd(nl); d.fac01 = wd(nl); d.fac10 = wd(nl); d.fac11 = wd(nl); d.selffac = wd(nl); d.selffrac = wd(nl); d.forfac = wd(nl);
-  d.forfrac = wd(nl); d.minorfrac = wd(nl); d.scaleminor = wd(nl); d.scaleminorn2 = wd(nl); d.colh2o = wd(nl); d.colco2 = wd(nl);
-  d.colo3 = wd(nl); d.coln2o = wd(nl); d.colco = wd(nl); d.colch4 = wd(nl); d.colo2 = wd(nl); d.colbrd = wd(nl); d.coldry = wd(nl);
-  d.wx1 = wd(nl); d.wx2 = wd(nl); d.wx3 = wd(nl); d.wx4 = wd(nl); d.secdiff = wd((size_t)N * 16);
-  std::vector<int32_t> idx(nl), laytrop(N), ncb(N, 1);
-  d.idx = idx.data(); d.laytrop = laytrop.data(); d.ncbands = ncb.data();
+  d.prep = wd(lw_prep_size(N, L)); d.secdiff = wd((size_t)N * 16);
+  std::vector<int32_t> laytrop(N), ncb(N, 1);
+  d.laytrop = laytrop.data(); d.ncbands = ncb.data();
   if (clouds) d.ctau = wd(nl * 16);
   d.nw = (L + 63) / 64;
   std::vector<uint64_t> mask, anym;
@@ -108,7 +105,7 @@ static void emu_taug_band(const LwDev &d, const LwTab &T, double *taug, double *
   for (int ig = 0; ig < T.b[BAND - 1].ng; ++ig)
     for (int l = 0; l < L; ++l) {
       LwLayerIn s;
-      lw_load_layer(d, (long)l * d.ncol, s);
+      lw_load_layer(d, 0, l, s);
       double fr;
       const double tg = lw_taug<BAND>(T, s, (l + 1) <= d.laytrop[0], ig, fr);
       taug[(size_t)(T.b[BAND - 1].gs + ig) * L + l] = tg;    // Fortran (nlay, ngpt) order
@@ -135,12 +132,9 @@ extern "C" int emu_lw_taumol(const rrtmg_lw_args *a, const char *blob_path, doub
   d.cfc22 = a->cfc22vmr; d.ccl4 = a->ccl4vmr; d.emis = a->emis;
   std::vector<std::vector<double>> keep;
   auto wd = [&](size_t n) { keep.emplace_back(n, 0.0); return keep.back().data(); };
-  d.fac00 = wd(L); d.fac01 = wd(L); d.fac10 = wd(L); d.fac11 = wd(L); d.selffac = wd(L); d.selffrac = wd(L); d.forfac = wd(L);
-  d.forfrac = wd(L); d.minorfrac = wd(L); d.scaleminor = wd(L); d.scaleminorn2 = wd(L); d.colh2o = wd(L); d.colco2 = wd(L);
-  d.colo3 = wd(L); d.coln2o = wd(L); d.colco = wd(L); d.colch4 = wd(L); d.colo2 = wd(L); d.colbrd = wd(L); d.coldry = wd(L);
-  d.wx1 = wd(L); d.wx2 = wd(L); d.wx3 = wd(L); d.wx4 = wd(L); d.secdiff = wd(16);
-  std::vector<int32_t> idx(L), laytrop(1);
-  d.idx = idx.data(); d.laytrop = laytrop.data();
+  d.prep = wd(lw_prep_size(1, L)); d.secdiff = wd(16);
+  std::vector<int32_t> laytrop(1);
+  d.laytrop = laytrop.data();
   int errflag = 0;
   d.err = &errflag;
   lw_prep_column(d, T, 0);

@@ -64,11 +64,9 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   if (d.iaer == 10) { d.tauaer = a->tauaer; d.ssaaer = a->ssaaer; d.asmaer = a->asmaer; }
   std::vector<std::vector<double>> keep;
   auto wd = [&](size_t n) { keep.emplace_back(n, 0.0); return keep.back().data(); };
-  d.fac00 = wd(nl); d.fac01 = wd(nl); d.fac10 = wd(nl); d.fac11 = wd(nl); d.selffac = wd(nl); d.selffrac = wd(nl);
-  d.forfac = wd(nl); d.forfrac = wd(nl); d.colh2o = wd(nl); d.colco2 = wd(nl); d.colo3 = wd(nl); d.colch4 = wd(nl);
-  d.colo2 = wd(nl); d.colmol = wd(nl); d.pdp = wd(nl); d.cossza = wd(N);
-  std::vector<int32_t> idx(nl), laytrop(N), laysolfr((size_t)N * kSwNBand), anycld(N);
-  d.idx = idx.data(); d.laytrop = laytrop.data(); d.laysolfr = laysolfr.data(); d.anycld = anycld.data();
+  d.prep = wd(sw_prep_size(N, L)); d.pdp = wd(nl); d.cossza = wd(N);
+  std::vector<int32_t> laytrop(N), laysolfr((size_t)N * kSwNBand), anycld(N);
+  d.laytrop = laytrop.data(); d.laysolfr = laysolfr.data(); d.anycld = anycld.data();
   if (d.icld >= 1) { d.ctau = wd(nl * kSwNBand); d.cssa = wd(nl * kSwNBand); d.casm = wd(nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   std::vector<uint64_t> mask;
