@@ -68,6 +68,7 @@ def load_library():
     lib.rrtmg_hip_get_table.argtypes = [_vp, C.c_char_p, _vp, C.c_long]
     lib.rrtmg_hip_lw_tables_synthetic.argtypes = [_vp]
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
+    lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
@@ -146,7 +147,12 @@ class Context:
         return ms.value
 
     def synchronize(self):
+        """Wait for all enqueued work; in deferred mode this is where device-side errors are raised."""
         self._ck(self.lib.rrtmg_hip_synchronize(self.h))
+
+    def set_deferred(self, on=True):
+        """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams."""
+        self._ck(self.lib.rrtmg_hip_set_deferred(self.h, 1 if on else 0))
 
     def get_table(self, name):
         n = self.lib.rrtmg_hip_get_table(self.h, name.encode(), None, 0)

@@ -29,6 +29,7 @@ const char *status_message(int code) {
 int ctx_prepare_device(rrtmg_ctx *ctx) {
   RRTMG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  if (!ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_lw, hipStreamNonBlocking));
   if (!ctx->err_dev) RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 2; ++k)
@@ -80,6 +81,7 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
   if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
   if (ctx->err_dev) (void)hipFree(ctx->err_dev);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->stream_lw) (void)hipStreamDestroy(ctx->stream_lw);
   rrtmg::free_sw_desc(ctx);
   rrtmg::free_lw_desc(ctx);
   delete ctx;
@@ -96,8 +98,24 @@ int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms) {
 }
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
   if (!ctx) return RRTMG_ERR_ARG;
-  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream_lw));
+  // deferred calls: collect the device-side error flags now (the former Fortran `stop` conditions)
+  if (ctx->pending[0] || ctx->pending[1]) {
+    int herr[2] = {0, 0};
+    RRTMG_HIP_CHECK(ctx, hipMemcpy(herr, ctx->err_dev, sizeof herr, hipMemcpyDeviceToHost));
+    const bool p0 = ctx->pending[0], p1 = ctx->pending[1];
+    ctx->pending[0] = ctx->pending[1] = false;
+    if (p0 && herr[0]) return ctx->fail(herr[0], "shortwave: %s", status_message(herr[0]));
+    if (p1 && herr[1]) return ctx->fail(herr[1], "longwave: %s", status_message(herr[1]));
+  }
   return RRTMG_OK;
+}
+int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  int rc = rrtmg_hip_synchronize(ctx);
+  ctx->deferred = on != 0;
+  return rc;
 }
 
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz, double clight,

@@ -23,7 +23,10 @@ struct DevBuf {
 
 struct rrtmg_ctx {
   int device = 0;
-  hipStream_t stream = nullptr;
+  hipStream_t stream = nullptr;      // shortwave (and everything else)
+  hipStream_t stream_lw = nullptr;   // longwave in deferred mode, so SW and LW launches overlap on the GPU
+  bool deferred = false;             // rrtmg_hip_set_deferred: device-resident calls return after enqueueing
+  bool pending[2] = {false, false};  // [sw|lw] enqueued, status not yet collected
   std::string err;
   int status = 0;
   rrtmg::Constants k{};

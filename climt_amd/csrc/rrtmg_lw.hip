@@ -49,7 +49,9 @@ struct LwBlockSink {
   }
   __device__ void dn(int lev, double rd, double rcd) {
     sh[phase][wave][0][lane] = rd; sh[phase][wave][1][lane] = rcd;
+#ifndef RRTMG_EXP_NOSYNC
     __syncthreads();
+#endif
     if (wave == 0) reduce_store(1, 0, lev);
     if (wave == 1) reduce_store(3, 1, lev);
     phase ^= 1;
@@ -57,7 +59,9 @@ struct LwBlockSink {
   __device__ void up(int lev, double ru, double rcu, double du, double dcu) {
     sh[phase][wave][0][lane] = ru; sh[phase][wave][1][lane] = rcu;
     if (idrv) { sh[phase][wave][2][lane] = du; sh[phase][wave][3][lane] = dcu; }
+#ifndef RRTMG_EXP_NOSYNC
     __syncthreads();
+#endif
     if (wave == 0) reduce_store(0, 0, lev);
     if (wave == 1) reduce_store(2, 1, lev);
     if (idrv && wave == 2) reduce_store(4, 2, lev);
@@ -66,7 +70,10 @@ struct LwBlockSink {
   }
 };
 
-__global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8, int tile_order) {
+#ifndef RRTMG_LW_WAVES
+#define RRTMG_LW_WAVES 3
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8, int tile_order) {
   __shared__ double sh[2][kLwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
@@ -76,13 +83,20 @@ __global__ void __launch_bounds__(256) lw_solve_all_kernel(LwDev d, LwTab T, int
   const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  const int iw = grp * kLwGroup + threadIdx.y;
+  // wavefront index as a SCALAR: g-point, band and every table offset derived from them stay in SGPRs and the
+  // band switch is a scalar branch
+#ifdef RRTMG_EXP_NOSCALAR
+  const int wave = threadIdx.y;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+#endif
+  const int iw = grp * kLwGroup + wave;
   int b = 0;
   while (b < kLwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
   const int ig = iw - T.b[b].gs;
   double *scr = d.scratch + ((long)tile * kLwNGpt + iw) * (long)LF_N * d.nlay * 64 + threadIdx.x;
   LwBlockSink sink;
-  sink.sh = sh; sink.N = d.ncol; sink.st = (long)(d.nlay + 1) * d.ncol; sink.wave = threadIdx.y; sink.lane = threadIdx.x;
+  sink.sh = sh; sink.N = d.ncol; sink.st = (long)(d.nlay + 1) * d.ncol; sink.wave = wave; sink.lane = threadIdx.x;
   sink.phase = 0; sink.idrv = d.idrv != 0;
   sink.p = d.part + ((long)grp * (d.idrv ? 6 : 4) * (d.nlay + 1)) * d.ncol + col;
   switch (b + 1) {
@@ -147,7 +161,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
   int rc = ctx_prepare_device(ctx);
   if (rc) return rc;
-  hipStream_t s = ctx->stream;
+  hipStream_t s = (ctx->deferred && a->memspace == 1) ? ctx->stream_lw : ctx->stream;
   const int N = a->ncol, L = a->nlay;
   const size_t nl = (size_t)N * L, nl1 = (size_t)N * (L + 1);
   const LwTab &T = *(LwTab *)ctx->lw_desc;
@@ -220,7 +234,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     if (d.idrv) { d.duflx_dt = wd("o.du", nl1); d.duflxc_dt = wd("o.duc", nl1); }
   }
   if (!ok) return ctx->status;
-  d.err = ctx->err_dev;
+  d.err = ctx->err_dev + 1;   // [0] shortwave, [1] longwave
   RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
 
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
@@ -259,6 +273,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
+  if (ctx->deferred && a->memspace == 1) { ctx->pending[1] = true; ctx->status = 0; return RRTMG_OK; }
   int herr = 0;
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
   if (a->memspace == 0) {

@@ -71,14 +71,19 @@ struct SwBlockSink {
   __device__ void emit(int lev, double fu, double fd, double cu, double cd) {
     const int pb = lev & 1;
     sh[pb][wave][0][lane] = fu; sh[pb][wave][1][lane] = fd; sh[pb][wave][2][lane] = cu; sh[pb][wave][3][lane] = cd;
+#ifndef RRTMG_EXP_NOSYNC
     __syncthreads();
+#endif
     double s = sh[pb][0][wave][lane];
     s = s + sh[pb][1][wave][lane]; s = s + sh[pb][2][wave][lane]; s = s + sh[pb][3][wave][lane];
     out[(long)lev * N] = s;
   }
 };
 
-__global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8, int tile_order) {
+#ifndef RRTMG_SW_WAVES
+#define RRTMG_SW_WAVES 5
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8, int tile_order) {
   __shared__ double sh[2][kSwGroup][4][64];
   const int q = blockIdx.x;
   const int xcd = q & 7, r = q >> 3;
@@ -88,15 +93,22 @@ __global__ void __launch_bounds__(256) sw_solve_all_kernel(SwDev d, SwTab T, int
   const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  const int iw = grp * kSwGroup + threadIdx.y;
+  // wavefront index as a SCALAR: g-point, band and every table offset derived from them stay in SGPRs and the
+  // band switch is a scalar branch
+#ifdef RRTMG_EXP_NOSCALAR
+  const int wave = threadIdx.y;
+#else
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
+#endif
+  const int iw = grp * kSwGroup + wave;
   // band of this wavefront's g-point (wave-uniform)
   int b = 0;
   while (b < kSwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
   const int ig = iw - T.b[b].gs;
   double *scr = d.scratch + ((long)tile * kSwNGpt + iw) * (long)F_NTOT * d.nlay * 64 + threadIdx.x;
   SwBlockSink sink;
-  sink.sh = sh; sink.N = d.ncol; sink.wave = threadIdx.y; sink.lane = threadIdx.x;
-  sink.out = d.part + (((long)grp * 4 + threadIdx.y) * (d.nlay + 1)) * d.ncol + col;
+  sink.sh = sh; sink.N = d.ncol; sink.wave = wave; sink.lane = threadIdx.x;
+  sink.out = d.part + (((long)grp * 4 + wave) * (d.nlay + 1)) * d.ncol + col;
   switch (b + 16) {
     case 16: sw_solve_thread<16>(d, T, col, ig, scr, 64, sink); break;
     case 17: sw_solve_thread<17>(d, T, col, ig, scr, 64, sink); break;
@@ -315,6 +327,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
   // ---- status + outputs -------------------------------------------------------------------
+  if (ctx->deferred && a->memspace == 1) { ctx->pending[0] = true; ctx->status = 0; return RRTMG_OK; }
   int herr = 0;
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
   if (a->memspace == 0) {

@@ -72,9 +72,14 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal);
 void rrtmg_hip_destroy(rrtmg_ctx *ctx);
 const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx);
 const char *rrtmg_hip_version(void);
-/* HIP stream (hipStream_t) all work of this context is enqueued on; for event timing. */
+/* HIP stream (hipStream_t) the work of this context is enqueued on (longwave uses a second one in deferred mode). */
 void *rrtmg_hip_stream(rrtmg_ctx *ctx);
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
+/* Deferred mode (off by default).  When on, rrtmg_hip_{sw,lw}_fluxes calls with memspace == 1 (device-resident
+ * arrays) return as soon as their kernels are enqueued -- shortwave and longwave on separate streams, so the two
+ * overlap on the GPU -- and the device-side error flags (the reference's `stop` conditions) are reported by the
+ * next rrtmg_hip_synchronize / rrtmg_hip_set_deferred call instead.  Host-memory calls stay synchronous. */
+int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
 /* Duration (ms, HIP events recorded on the context's stream) of the dominant kernel of the last completed
  * call: which = 0 -> sw_solve_all_kernel, 1 -> lw_solve_all_kernel.  Returns RRTMG_ERR_ARG if never run. */
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
