@@ -25,8 +25,6 @@ RRTMG_HD void report_error(int *flag, int code) {
 #endif
 }
 
-// Transmittance lookup index: itind = tblint*x/(bpade+x) + 0.5 truncated (rrtmg_sw_reftra.f90:199-203,
-// rrtmg_lw_rtrn.f90:426-430).  Index arithmetic stays in fp64 so table entries do not flip.
 // Quick fp64 division for the flux arithmetic of the hot loops: v_rcp_f64 + two Newton-Raphson steps
 // (<= ~1 ulp) instead of the 11-instruction IEEE sequence (div_scale x2, rcp, 6 fma, div_fmas, div_fixup) --
 // divisions were ~60 % of the VALU instructions of the solve kernels.  Operands here are O(1e-20..1e20) and
@@ -44,6 +42,55 @@ RRTMG_HD double qdiv(double a, double b) {
 }
 RRTMG_HD double qrcp(double b) { return qdiv(1.0, b); }
 
+// ------------------------------------------------------------------------------------------------------
+// G consecutive g-points of one band, carried through the k-distribution arithmetic by one thread.  Everything
+// that does not depend on the g-point (layer state, species mixtures, interpolation weights, table rows) is
+// computed once and the G table entries of a row come from ONE 16-byte-granular load, because the reduced
+// tables are stored g-point-fastest ([row][ng]).  Element-wise operators keep the reference's operation order
+// per g-point.
+// ------------------------------------------------------------------------------------------------------
+template <int G> struct V {
+  double v[G];
+  RRTMG_HD double &operator[](int i) { return v[i]; }
+  RRTMG_HD double operator[](int i) const { return v[i]; }
+};
+#define RRTMG_VOP(OP)                                                                                       \
+  template <int G> RRTMG_HD V<G> operator OP(const V<G> &a, const V<G> &b) { V<G> r; _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = a.v[i] OP b.v[i]; return r; } \
+  template <int G> RRTMG_HD V<G> operator OP(const V<G> &a, double b) { V<G> r; _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = a.v[i] OP b; return r; }           \
+  template <int G> RRTMG_HD V<G> operator OP(double a, const V<G> &b) { V<G> r; _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = a OP b.v[i]; return r; }
+RRTMG_VOP(+)
+RRTMG_VOP(-)
+RRTMG_VOP(*)
+#undef RRTMG_VOP
+template <int G> RRTMG_HD V<G> vsplat(double x) { V<G> r; _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = x; return r; }
+
+// G consecutive doubles at p; p is 16-byte aligned (tables are 16-byte aligned, ng and the first g-point of a
+// work item are even)
+template <int G> RRTMG_HD V<G> vload(const double *p) {
+  V<G> r;
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (G % 2 == 0) {
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) {
+      const double2 x = *reinterpret_cast<const double2 *>(p + i);
+      r.v[i] = x.x; r.v[i + 1] = x.y;
+    }
+    return r;
+  }
+#endif
+  _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = p[i];
+  return r;
+}
+
+// g-point-fastest table view: element (row, ig0 + j) at p[row * NG + j], p already offset by the first g-point
+template <int G, int NG> struct KTab {
+  const double *p;
+#ifdef RRTMG_ABL_UNIFORMK
+  RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)(row & 1) * NG); }
+#else
+  RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)row * NG); }
+#endif
+};
+
 // bit l of a 4-word (<= 256 layers) cloud mask held in registers: selects instead of dynamic indexing, which
 // would push the array into private (scratch) memory
 RRTMG_HD bool mask_bit(const uint64_t *w, int l) {
@@ -51,6 +98,8 @@ RRTMG_HD bool mask_bit(const uint64_t *w, int l) {
   return (v >> (l & 63)) & 1ull;
 }
 
+// Transmittance lookup index: itind = tblint*x/(bpade+x) + 0.5 truncated (rrtmg_sw_reftra.f90:199-203,
+// rrtmg_lw_rtrn.f90:426-430).  Index arithmetic stays in fp64 so table entries do not flip.
 constexpr double kTblInt = 10000.0;
 constexpr double kBpade = 1.0 / 0.278;
 

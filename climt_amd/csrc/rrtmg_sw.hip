@@ -5,7 +5,7 @@
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
 //   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
 //   sw_kiss_kernel / mask upload (mcica)         sub-column cloud mask
-//   sw_solve_all_kernel one launch: grid = tiles(64 columns) x 28 g-groups (XCD-aware), block = 4 wavefronts
+//   sw_solve_all_kernel one launch: grid = tiles(64 columns) x work items (4|2 g-points of a band), block = 1 wavefront
 //   sw_flux_kernel      <<<ncol/64, nlay+1>>>    g-point sum per interface
 //   sw_heat_kernel      <<<ncol/64, nlay>>>      heating rates
 #include "rrtmg_ctx.h"
@@ -53,83 +53,38 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
   }
 }
 
-// All 112 g-points in ONE launch.  Block = 4 wavefronts = 4 consecutive g-points of one 64-column tile
-// (they share the tile's prep rows through L1); grid = 28 g-groups x tiles.  blockIdx -> (tile, group) is
-// XCD-aware: the dispatcher places block b on XCD b % 8, so every block of a tile is given the same
-// residue and the tile's prep arrays / k-table slices stay in ONE XCD's L2 (speed only, never correctness).
-constexpr int kSwGroup = 4;
-
-// Flux sink of the device kernel: the 4 wavefronts (g-points) of a block add their weighted fluxes through LDS
-// at every interface and the block writes ONE partial per quantity -- part[g-group][k][level][column] -- so the
-// spectral integration reads 28 instead of 112 partials.  Fixed summation order -> deterministic, shard-exact.
-// Double-buffered by level parity: one __syncthreads per level.
-struct SwBlockSink {
-  double (*sh)[kSwGroup][4][64];
-  double *out;   // part + ((grp*4 + wave) * (L+1)) * N + col  (wave w reduces quantity k = w)
-  long N;
-  int wave, lane;
-  __device__ void emit(int lev, double fu, double fd, double cu, double cd) {
-    const int pb = lev & 1;
-    sh[pb][wave][0][lane] = fu; sh[pb][wave][1][lane] = fd; sh[pb][wave][2][lane] = cu; sh[pb][wave][3][lane] = cd;
-#ifndef RRTMG_EXP_NOSYNC
-    __syncthreads();
-#endif
-    double s = sh[pb][0][wave][lane];
-    s = s + sh[pb][1][wave][lane]; s = s + sh[pb][2][wave][lane]; s = s + sh[pb][3][wave][lane];
-    out[(long)lev * N] = s;
-  }
-};
-
+// All 112 g-points in ONE launch.  Wavefront = 64 columns of one tile x one work item (2 consecutive g-points
+// of a band, SwTab::item): the thread carries the item's g-points through both sweeps, so the layer state, species
+// mixtures and interpolation weights are evaluated once per item and every table row is one 16-byte load; the
+// item's weighted fluxes are summed in registers: part[item][k][level][column].
+// Workgroup = 8 wavefronts = the same item for 8 consecutive tiles (equal run times), sharing ONE copy of the
+// 10001-entry transmittance table in LDS (80 KB, two workgroups per CU): its lookups are per-lane random and
+// cost a tag lookup per lane in the vector L1, but only bank conflicts in LDS.
+// Launch order: items heaviest first (SwTab::sched), tile groups fastest.  Speed only, never correctness.
 #ifndef RRTMG_SW_WAVES
-#define RRTMG_SW_WAVES 5
+#define RRTMG_SW_WAVES 4
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile8, int tile_order) {
-  __shared__ double sh[2][kSwGroup][4][64];
+constexpr int kSwWgWaves = 8;
+constexpr int kExpTblN = 10001;
+__global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile) {
+  __shared__ double sh_exp[kExpTblN];
+  for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x;
-  const int xcd = q & 7, r = q >> 3;
-  const int ngrp = kSwNGpt / kSwGroup;
-  const int nt = ntile8 >> 3;   // tiles per XCD
-  const int grp = tile_order ? r / nt : r % ngrp;
-  const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
-  const int col = tile * 64 + threadIdx.x;
+  const int tile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;
+  const int item = T.item[T.sched[k]], slot = T.sched[k];
+  const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
-  // wavefront index as a SCALAR: g-point, band and every table offset derived from them stay in SGPRs and the
-  // band switch is a scalar branch
-#ifdef RRTMG_EXP_NOSCALAR
-  const int wave = threadIdx.y;
-#else
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-#endif
-  const int iw = grp * kSwGroup + wave;
-  // band of this wavefront's g-point (wave-uniform)
-  int b = 0;
-  while (b < kSwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
-  const int ig = iw - T.b[b].gs;
-  double *scr = d.scratch + ((long)tile * kSwNGpt + iw) * (long)F_NTOT * d.nlay * 64 + threadIdx.x;
-  SwBlockSink sink;
-  sink.sh = sh; sink.N = d.ncol; sink.wave = wave; sink.lane = threadIdx.x;
-  sink.out = d.part + (((long)grp * 4 + wave) * (d.nlay + 1)) * d.ncol + col;
-  switch (b + 16) {
-    case 16: sw_solve_thread<16>(d, T, col, ig, scr, 64, sink); break;
-    case 17: sw_solve_thread<17>(d, T, col, ig, scr, 64, sink); break;
-    case 18: sw_solve_thread<18>(d, T, col, ig, scr, 64, sink); break;
-    case 19: sw_solve_thread<19>(d, T, col, ig, scr, 64, sink); break;
-    case 20: sw_solve_thread<20>(d, T, col, ig, scr, 64, sink); break;
-    case 21: sw_solve_thread<21>(d, T, col, ig, scr, 64, sink); break;
-    case 22: sw_solve_thread<22>(d, T, col, ig, scr, 64, sink); break;
-    case 23: sw_solve_thread<23>(d, T, col, ig, scr, 64, sink); break;
-    case 24: sw_solve_thread<24>(d, T, col, ig, scr, 64, sink); break;
-    case 25: sw_solve_thread<25>(d, T, col, ig, scr, 64, sink); break;
-    case 26: sw_solve_thread<26>(d, T, col, ig, scr, 64, sink); break;
-    case 27: sw_solve_thread<27>(d, T, col, ig, scr, 64, sink); break;
-    case 28: sw_solve_thread<28>(d, T, col, ig, scr, 64, sink); break;
-    default: sw_solve_thread<29>(d, T, col, ig, scr, 64, sink); break;
-  }
+  double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63);
+  SwPartSink sink = sw_part_sink(d, slot, col);
+  sw_solve_item(d, T, sh_exp, item, col, scr, 64, sink);
 }
 
-__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d) {
+__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, int nparts) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y, kSwNGpt / kSwGroup);
+  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y, nparts);
 }
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -275,7 +230,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
   d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
-  d.part = wd("part", (size_t)(kSwNGpt / kSwGroup) * 4 * nl1);
+  d.part = wd("part", (size_t)T.nitem * 4 * nl1);
   if (a->memspace == 1) {
     d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   } else {
@@ -315,14 +270,11 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       }
     }
   }
-  {
-    const int ntile8 = (ntile + 7) / 8 * 8;
-    (void)hipEventRecord(ctx->ev[0][0], s);
-    hipLaunchKernelGGL(sw_solve_all_kernel, dim3(ntile8 * (kSwNGpt / kSwGroup)), dim3(64, kSwGroup), 0, s, d, T, ntile8, ctx->tile_order);
-    (void)hipEventRecord(ctx->ev[0][1], s);
-    ctx->ev_valid[0] = true;
-  }
-  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d);
+  (void)hipEventRecord(ctx->ev[0][0], s);
+  hipLaunchKernelGGL(sw_solve_all_kernel, dim3((ntile + kSwWgWaves - 1) / kSwWgWaves * T.nitem), dim3(64 * kSwWgWaves), 0, s, d, T, ntile);
+  (void)hipEventRecord(ctx->ev[0][1], s);
+  ctx->ev_valid[0] = true;
+  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T.nitem);
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -29,15 +29,29 @@ constexpr int kSwNGpt = 112;
 struct SwBandTab {
   int ng, gs;       // g-points in band, first g-point (0-based) of band
   int nfor, nsrc;   // rows of forref (3|4); source mixtures (1, 5 or 9)
-  long absa, absb, self, forr;
+  long absa, absb, self, forr;   // g-point-fastest copies: [row][ng]
   long sflux, irr, fac, sns;   // [js][ig]
   long rayl, raylb;            // rayl: [ng] (or [9][ng] band 24); raylb band 24 upper
   long ex1, ex2;               // extra absorber tables (lower / upper)
 };
 
+// Work item of the solve kernel: G (4 or 2) consecutive g-points of one band, carried by one thread per column.
+// Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Item order = g-point order
+// (it is the partial-flux slot); sched[] lists the items heaviest first (launch order).
+constexpr int kSwMaxItem = 56;
+#ifndef RRTMG_GMAX
+#define RRTMG_GMAX 2
+#endif
+RRTMG_HD int item_band(int it) { return it & 0xff; }
+RRTMG_HD int item_ig0(int it) { return (it >> 8) & 0xff; }
+RRTMG_HD int item_g(int it) { return (it >> 16) & 0xf; }
+RRTMG_HD int item_iw0(int it) { return (it >> 20) & 0xff; }
+
 struct SwTab {
   const double *t;
   SwBandTab b[kSwNBand];
+  int nitem;
+  int32_t item[kSwMaxItem], sched[kSwMaxItem];
   long preflog, tref, exp_tbl;
   long extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3;
   long abari, bbari, cbari, dbari, ebari, fbari, wavenum2;
@@ -70,8 +84,8 @@ struct SwDev {
   double *ctau, *cssa, *casm;   // delta-scaled cloud optics [14][lay][col]
   uint64_t *mask;      // McICA cloud mask bits [112][nw][col]
   int nw;
-  double *scratch;     // [tile][g-point][lay][field][64]
-  double *part;        // [112][4][nlay+1][col]  weighted (fu, fd, cu, cd)
+  double *scratch;     // [tile][item: first g-point * ...][lay][field][G][64]
+  double *part;        // [item][4][nlay+1][col]  weighted (fu, fd, cu, cd), summed over the item's g-points
   int *err;
   // outputs
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
@@ -396,35 +410,49 @@ RRTMG_HD void kiss_mask_column(int ncol, int nlay, int nsub, int icld, int chang
 // ------------------------------------------------------------------------------------------
 // transmittance table / two-stream layer operators
 // ------------------------------------------------------------------------------------------
+// (the quotient is the quick division: a last-place difference moves the rounded index with probability ~1e-12
+//  per lookup, to a neighbouring entry 1e-4 away -- far inside the 0.01 W m-2 bar)
 RRTMG_HD double sw_exp_lookup(const double *exp_tbl, double x) {
-  const double tblind = x / (kBpade + x);
+  const double tblind = qdiv(x, kBpade + x);
   const int itind = (int)(kTblInt * tblind + 0.5);
   return exp_tbl[itind];
 }
 
 // direct-beam transmittance of a layer (rrtmg_sw_spcvrt.f90:562-574)
-RRTMG_HD double sw_dbt(const double *exp_tbl, double tau, double prmu0) {
-  const double ze1 = tau / prmu0;
+// rmu0 = 1/prmu0, formed once per column: tau/prmu0 is evaluated as tau*rmu0 (<= 1 ulp apart)
+RRTMG_HD double sw_dbt(const double *exp_tbl, double tau, double rmu0) {
+  const double ze1 = tau * rmu0;
   if (ze1 <= 0.06) return 1.0 - ze1 + 0.5 * ze1 * ze1;
   return sw_exp_lookup(exp_tbl, ze1);
 }
 
 // reftra_sw for one layer, kmodts = 2 (rrtmg_sw_reftra.f90:148-316)
-RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double zto1, double zw, double &pref,
+// ZG0: the asymmetry parameter is exactly zero (clear sky without aerosol) -- the same arithmetic with the
+// terms that are then exactly 0 / 1 folded at compile time (identical results).  rmuz = 1/prmuz.
+template <bool ZG0 = false>
+RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double rmuz, double zto1, double zw, double &pref,
                         double &prefd, double &ptra, double &ptrad) {
   const double eps = 1.e-08, zwcrit = 0.9999995, od_lo = 0.06;
-  const double zg3 = 3.0 * zg;
-  const double zgamma1 = (8.0 - zw * (5.0 + zg3)) * 0.25;
-  const double zgamma2 = 3.0 * (zw * (1.0 - zg)) * 0.25;
-  const double zgamma3 = (2.0 - zg3 * prmuz) * 0.25;
+  double zgamma1, zgamma2, zgamma3, zwo;
+  if constexpr (ZG0) {
+    zgamma1 = (8.0 - zw * 5.0) * 0.25;
+    zgamma2 = 3.0 * zw * 0.25;
+    zgamma3 = 0.5;
+    zwo = zw;
+  } else {
+    const double zg3 = 3.0 * zg;
+    zgamma1 = (8.0 - zw * (5.0 + zg3)) * 0.25;
+    zgamma2 = 3.0 * (zw * (1.0 - zg)) * 0.25;
+    zgamma3 = (2.0 - zg3 * prmuz) * 0.25;
+    const double zq = qdiv(zg, 1.0 - zg);
+    zwo = qdiv(zw, 1.0 - (1.0 - zw) * (zq * zq));
+  }
   const double zgamma4 = 1.0 - zgamma3;
-  const double zq = qdiv(zg, 1.0 - zg);
-  const double zwo = qdiv(zw, 1.0 - (1.0 - zw) * (zq * zq));
   if (zwo >= zwcrit) {
     const double za = zgamma1 * prmuz;
     const double za1 = za - zgamma3;
     const double zgt = zgamma1 * zto1;
-    double ze1 = zto1 / prmuz;
+    double ze1 = zto1 * rmuz;
     if (ze1 > 500.0) ze1 = 500.0;
     double ze2;
     if (ze1 <= od_lo) ze2 = 1.0 - ze1 + 0.5 * ze1 * ze1; else ze2 = sw_exp_lookup(exp_tbl, ze1);
@@ -452,7 +480,7 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double z
     const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
     const double zbeta = qdiv(zgamma1 - zrk, zrkg);
     double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
-    double ze2 = zto1 / prmuz; if (ze2 > 500.0) ze2 = 500.0;
+    double ze2 = zto1 * rmuz; if (ze2 > 500.0) ze2 = 500.0;
     double zem1, zem2;
     if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
     const double zep1 = qrcp(zem1);
@@ -506,8 +534,9 @@ RRTMG_HD SwSpec sw_specparm(double colx, double coly, double strrat, double mult
   return r;
 }
 
-// 8-point (binary species) major-gas sum, d1/d2 = offsets of the next-temperature rows
-RRTMG_HD double sw_m8(const double *k, int i0, int i1, int dT, const SwLayerIn &s, double fs) {
+// 8-point (binary species) major-gas sum, dT = offset of the next-temperature rows
+template <int G, int NG>
+RRTMG_HD V<G> sw_m8(const KTab<G, NG> &k, int i0, int i1, int dT, const SwLayerIn &s, double fs) {
   const double fac000 = (1.0 - fs) * s.fac00, fac010 = (1.0 - fs) * s.fac10;
   const double fac100 = fs * s.fac00, fac110 = fs * s.fac10;
   const double fac001 = (1.0 - fs) * s.fac01, fac011 = (1.0 - fs) * s.fac11;
@@ -515,72 +544,75 @@ RRTMG_HD double sw_m8(const double *k, int i0, int i1, int dT, const SwLayerIn &
   return fac000 * k[i0] + fac100 * k[i0 + 1] + fac010 * k[i0 + dT] + fac110 * k[i0 + dT + 1] +
          fac001 * k[i1] + fac101 * k[i1 + 1] + fac011 * k[i1 + dT] + fac111 * k[i1 + dT + 1];
 }
-RRTMG_HD double sw_m4(const double *k, int i0, int i1, const SwLayerIn &s) {
+template <int G, int NG>
+RRTMG_HD V<G> sw_m4(const KTab<G, NG> &k, int i0, int i1, const SwLayerIn &s) {
   return s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1];
 }
-RRTMG_HD double sw_selfterm(const double *selfref, const SwLayerIn &s) {  // selffac*(selfref + selffrac*(d))
-  const double a = selfref[s.indself - 1], b = selfref[s.indself];
+template <int G, int NG>
+RRTMG_HD V<G> sw_selfterm(const KTab<G, NG> &selfref, const SwLayerIn &s) {  // selffac*(selfref + selffrac*(d))
+  const V<G> a = selfref[s.indself - 1], b = selfref[s.indself];
   return s.selffac * (a + s.selffrac * (b - a));
 }
-RRTMG_HD double sw_forinterp(const double *forref, const SwLayerIn &s) {  // forref + forfrac*(d)
-  const double a = forref[s.indfor - 1], b = forref[s.indfor];
+template <int G, int NG>
+RRTMG_HD V<G> sw_forinterp(const KTab<G, NG> &forref, const SwLayerIn &s) {  // forref + forfrac*(d)
+  const V<G> a = forref[s.indfor - 1], b = forref[s.indfor];
   return a + s.forfrac * (b - a);
 }
 
 template <int BAND> struct SwBandCfg;
-#define SW_CFG(B, NSPA, NSPB, LOX, LOY, STR, UPPERSRC, BINSRC)                     \
+#define SW_CFG(B, NG, NSPA, NSPB, LOX, LOY, STR, UPPERSRC, BINSRC)                 \
   template <> struct SwBandCfg<B> {                                                \
-    static constexpr int nspa = NSPA, nspb = NSPB, lox = LOX, loy = LOY;           \
+    static constexpr int ng = NG, nspa = NSPA, nspb = NSPB, lox = LOX, loy = LOY;  \
     static constexpr double strrat = STR;                                          \
     static constexpr bool upper_src = UPPERSRC, bin_src = BINSRC;                  \
   };
-//      band nspa nspb key-lo-x  key-lo-y  strrat        src-in-upper  binary-src
-SW_CFG(16, 9, 1, SP_H2O, SP_CH4, 252.131, true, false)
-SW_CFG(17, 9, 5, SP_H2O, SP_CO2, 0.364641, true, true)
-SW_CFG(18, 9, 1, SP_H2O, SP_CH4, 38.9589, false, true)
-SW_CFG(19, 9, 1, SP_H2O, SP_CO2, 5.49281, false, true)
-SW_CFG(20, 1, 1, SP_H2O, -1, 0.0, false, false)
-SW_CFG(21, 9, 5, SP_H2O, SP_CO2, 0.0045321, false, true)
-SW_CFG(22, 9, 1, SP_H2O, SP_O2, 1.6 * 0.022708, false, true)
-SW_CFG(23, 1, 0, SP_H2O, -1, 0.0, false, false)
-SW_CFG(24, 9, 1, SP_H2O, SP_O2, 0.124692, false, true)
-SW_CFG(25, 1, 0, SP_H2O, -1, 0.0, false, false)
-SW_CFG(26, 0, 0, -1, -1, 0.0, false, false)
-SW_CFG(27, 1, 1, SP_O3, -1, 0.0, true, false)
-SW_CFG(28, 9, 5, SP_O3, SP_O2, 6.67029e-07, true, true)
-SW_CFG(29, 1, 1, SP_H2O, -1, 0.0, true, false)
+//      band ng(reduced, rrtmg_sw parrrsw.f90 ng16..ng29) nspa nspb key-lo-x  key-lo-y  strrat  src-in-upper  binary-src
+SW_CFG(16, 6, 9, 1, SP_H2O, SP_CH4, 252.131, true, false)
+SW_CFG(17, 12, 9, 5, SP_H2O, SP_CO2, 0.364641, true, true)
+SW_CFG(18, 8, 9, 1, SP_H2O, SP_CH4, 38.9589, false, true)
+SW_CFG(19, 8, 9, 1, SP_H2O, SP_CO2, 5.49281, false, true)
+SW_CFG(20, 10, 1, 1, SP_H2O, -1, 0.0, false, false)
+SW_CFG(21, 10, 9, 5, SP_H2O, SP_CO2, 0.0045321, false, true)
+SW_CFG(22, 2, 9, 1, SP_H2O, SP_O2, 1.6 * 0.022708, false, true)
+SW_CFG(23, 10, 1, 0, SP_H2O, -1, 0.0, false, false)
+SW_CFG(24, 8, 9, 1, SP_H2O, SP_O2, 0.124692, false, true)
+SW_CFG(25, 6, 1, 0, SP_H2O, -1, 0.0, false, false)
+SW_CFG(26, 6, 0, 0, -1, -1, 0.0, false, false)
+SW_CFG(27, 8, 1, 1, SP_O3, -1, 0.0, true, false)
+SW_CFG(28, 6, 9, 5, SP_O3, SP_O2, 6.67029e-07, true, true)
+SW_CFG(29, 12, 1, 1, SP_H2O, -1, 0.0, true, false)
 #undef SW_CFG
 
 RRTMG_HD double sw_col(const SwLayerIn &s, int sp) {
   return sp == SP_H2O ? s.colh2o : sp == SP_CO2 ? s.colco2 : sp == SP_O3 ? s.colo3 : sp == SP_CH4 ? s.colch4 : s.colo2;
 }
 
-// Returns gas optical depth; sets Rayleigh optical depth. `lower` = layer index <= laytrop.
-template <int BAND>
-RRTMG_HD double sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig, double &taur) {
+// Gas optical depths of the G g-points ig0 .. ig0+G-1; sets the Rayleigh optical depths.
+// `lower` = layer index <= laytrop.
+template <int BAND, int G>
+RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V<G> &taur) {
   using C = SwBandCfg<BAND>;
+  constexpr int NG = C::ng;
   const SwBandTab &B = T.b[BAND - 16];
   const double *t = T.t;
-  const double *absa = t + B.absa + (long)ig * 65 * C::nspa;
-  const double *absb = t + B.absb + (long)ig * 235 * C::nspb;
-  const double *selfref = t + B.self + (long)ig * 10;
-  const double *forref = t + B.forr + (long)ig * B.nfor;
-  double taug = 0.0;
+  const KTab<G, NG> absa{t + B.absa + ig0}, absb{t + B.absb + ig0}, selfref{t + B.self + ig0}, forref{t + B.forr + ig0};
+  auto row = [&](long base) { return vload<G>(t + base + ig0); };   // a [ng] table
+  V<G> taug = vsplat<G>(0.0);
   // Rayleigh: scalar per band (replicated per g at init), per g, or band 24's mixture-dependent form
-  double rayl = t[B.rayl + ig];
+  V<G> rayl = row(B.rayl);
   if (lower) {
     if constexpr (C::nspa == 9) {
       const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, 8.0);
       const int i0 = ((s.jp - 1) * 5 + (s.jt - 1)) * 9 + sp.js - 1;
       const int i1 = (s.jp * 5 + (s.jt1 - 1)) * 9 + sp.js - 1;
-      const double major = sp.speccomb * sw_m8(absa, i0, i1, 9, s, sp.fs);
+      const V<G> major = sp.speccomb * sw_m8(absa, i0, i1, 9, s, sp.fs);
       if constexpr (BAND == 28) {
         taug = major;
       } else if constexpr (BAND == 24) {
-        taug = major + s.colo3 * t[B.ex1 + ig] +
+        taug = major + s.colo3 * row(B.ex1) +
                s.colh2o * (sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
-        const double *ra = t + B.rayl;   // rayla(ig, js): [js][ig]
-        const double r0 = ra[ig + B.ng * (sp.js - 1)], r1 = ra[ig + B.ng * sp.js];
+        const KTab<G, NG> ra{t + B.rayl + ig0};   // rayla(ig, js): [js][ig]
+        const V<G> r0 = ra[sp.js - 1], r1 = ra[sp.js];
         rayl = r0 + sp.fs * (r1 - r0);
       } else {
         taug = major + s.colh2o * (sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
@@ -589,27 +621,27 @@ RRTMG_HD double sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig, 
     } else if constexpr (C::nspa == 1) {
       const int i0 = ((s.jp - 1) * 5 + (s.jt - 1));
       const int i1 = (s.jp * 5 + (s.jt1 - 1));
-      const double m4 = sw_m4(absa, i0, i1, s);
+      const V<G> m4 = sw_m4(absa, i0, i1, s);
       if constexpr (BAND == 20) {
-        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colch4 * t[B.ex1 + ig];
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.ex1);
       } else if constexpr (BAND == 29) {
-        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colco2 * t[B.ex1 + ig];
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colco2 * row(B.ex1);
       } else if constexpr (BAND == 23) {
         taug = s.colh2o * (1.029 * m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
       } else if constexpr (BAND == 25) {
-        taug = s.colh2o * m4 + s.colo3 * t[B.ex1 + ig];
+        taug = s.colh2o * m4 + s.colo3 * row(B.ex1);
       } else {  // 27
         taug = s.colo3 * m4;
       }
     } else {
-      taug = 0.0;  // band 26
+      taug = vsplat<G>(0.0);  // band 26
     }
   } else {
     if constexpr (C::nspb == 5) {
       const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, 4.0);
       const int i0 = ((s.jp - 13) * 5 + (s.jt - 1)) * 5 + sp.js - 1;
       const int i1 = ((s.jp - 12) * 5 + (s.jt1 - 1)) * 5 + sp.js - 1;
-      const double major = sp.speccomb * sw_m8(absb, i0, i1, 5, s, sp.fs);
+      const V<G> major = sp.speccomb * sw_m8(absb, i0, i1, 5, s, sp.fs);
       if constexpr (BAND == 28) taug = major;
       else taug = major + s.colh2o * s.forfac * sw_forinterp(forref, s);
     } else if constexpr (C::nspb == 1) {
@@ -619,14 +651,14 @@ RRTMG_HD double sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig, 
       else if constexpr (BAND == 19) taug = s.colco2 * sw_m4(absb, i0, i1, s);
       else if constexpr (BAND == 20)
         taug = s.colh2o * (s.fac00 * absb[i0] + s.fac10 * absb[i0 + 1] + s.fac01 * absb[i1] + s.fac11 * absb[i1 + 1] +
-                           s.forfac * sw_forinterp(forref, s)) + s.colch4 * t[B.ex1 + ig];
+                           s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.ex1);
       else if constexpr (BAND == 22) taug = s.colo2 * 1.6 * sw_m4(absb, i0, i1, s) + 4.35e-4 * s.colo2 / (350.0 * 2.0);
-      else if constexpr (BAND == 24) { taug = s.colo2 * sw_m4(absb, i0, i1, s) + s.colo3 * t[B.ex2 + ig]; rayl = t[B.raylb + ig]; }
+      else if constexpr (BAND == 24) { taug = s.colo2 * sw_m4(absb, i0, i1, s) + s.colo3 * row(B.ex2); rayl = row(B.raylb); }
       else if constexpr (BAND == 27) taug = s.colo3 * sw_m4(absb, i0, i1, s);
-      else taug = s.colco2 * sw_m4(absb, i0, i1, s) + s.colh2o * t[B.ex2 + ig];  // 29
+      else taug = s.colco2 * sw_m4(absb, i0, i1, s) + s.colh2o * row(B.ex2);  // 29
     } else {
-      if constexpr (BAND == 25) taug = s.colo3 * t[B.ex2 + ig];
-      else taug = 0.0;  // 23, 26
+      if constexpr (BAND == 25) taug = s.colo3 * row(B.ex2);
+      else taug = vsplat<G>(0.0);  // 23, 26
     }
   }
   taur = s.colmol * rayl;
@@ -677,8 +709,8 @@ enum { F_RUP = 0, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
 // optical properties of one layer for one g-point: clear sky and (if requested) total sky
 struct SwLayerOpt { double ref, refd, tra, trad, dbt; };
 
-// Per-g-point flux sink used by the host emulation and by tests: weighted (fu, fd, cu, cd) of every g-point go
-// to part[g][k][level][column]; the device kernel uses a block-reducing sink instead (rrtmg_sw.hip).
+// Per-item flux sink used by the host emulation, by tests and by the device kernel: the weighted
+// (fu, fd, cu, cd), already summed over the item's g-points, go to part[item][k][level][column].
 struct SwPartSink {
   double *pfu, *pfd, *pcu, *pcd;
   long N;
@@ -686,180 +718,269 @@ struct SwPartSink {
     pfu[(long)lev * N] = fu; pfd[(long)lev * N] = fd; pcu[(long)lev * N] = cu; pcd[(long)lev * N] = cd;
   }
 };
-RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int iw, int col) {
+RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int slot, int col) {
   const long N = d.ncol, L1 = d.nlay + 1;
   SwPartSink s;
   s.N = N;
-  s.pfu = d.part + (((long)iw * 4 + 0) * L1) * N + col; s.pfd = d.part + (((long)iw * 4 + 1) * L1) * N + col;
-  s.pcu = d.part + (((long)iw * 4 + 2) * L1) * N + col; s.pcd = d.part + (((long)iw * 4 + 3) * L1) * N + col;
+  s.pfu = d.part + (((long)slot * 4 + 0) * L1) * N + col; s.pfd = d.part + (((long)slot * 4 + 1) * L1) * N + col;
+  s.pcu = d.part + (((long)slot * 4 + 2) * L1) * N + col; s.pcd = d.part + (((long)slot * 4 + 3) * L1) * N + col;
   return s;
 }
 
-// per-thread constants of a (column, g-point)
-struct SwThreadCtx {
-  int b, iw, ig, laytrop;
-  double prmu0;
-  bool cloudy_col;
-  uint64_t mw[4];
+// per-thread constants of a (column, work item)
+template <int G> struct SwThreadCtx {
+  int b, iw0, ig0, laytrop;
+  double prmu0, rmu0;      // cosine of the solar zenith angle and its reciprocal
+  const double *exp_tbl;   // transmittance table: the workgroup's LDS copy on the device, T.t + T.exp_tbl on the host
+  bool cloudy[G];   // any cloud in (sub-)column g
+  bool any_cloudy;
 };
 
-// taumol + delta scaling + reftra (+ cloud) for layer l: everything the two adding-method sweeps need.
-// Called in BOTH sweeps: recomputing it is cheaper than spilling five more level arrays through HBM
-// (the kernel was HBM-bound on that scratch traffic: profiles/r01_pmc_*.txt).
-template <int BAND>
-RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx &c, int col, int l, SwLayerOpt &clr, SwLayerOpt &tot) {
+// McICA cloud-mask bit of (sub-column iw, layer l): one 8-byte read from the [iw][word][col] bit mask
+RRTMG_HD bool sw_mask_bit(const SwDev &d, int iw, int col, int l) {
+  return (d.mask[((long)iw * d.nw + (l >> 6)) * d.ncol + col] >> (l & 63)) & 1ull;
+}
+
+// taumol + delta scaling + reftra (+ cloud) for layer l and the G g-points of the item: everything the two
+// adding-method sweeps need.  The layer state, the species mixture, the interpolation weights and the table
+// rows are evaluated ONCE for the G g-points.  Called in BOTH sweeps: recomputing it is cheaper than spilling
+// five more level arrays per g-point through HBM (profiles/r01_pmc_*.txt).
+template <int BAND, int G>
+RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<G> &c, int col, int l,
+                              SwLayerOpt (&clr)[G], SwLayerOpt (&tot)[G]) {
   const int L = d.nlay, N = d.ncol;
-  const double *exp_tbl = T.t + T.exp_tbl;
-  const double prmu0 = c.prmu0;
+  const double *exp_tbl = c.exp_tbl;
+  const double prmu0 = c.prmu0, rmu0 = c.rmu0;
   const long i = (long)l * N + col;
   SwLayerIn s;
   sw_load_layer(d, col, l, s);
-  double taur;
-  const double taug = sw_taug<BAND>(T, s, (l + 1) <= c.laytrop, c.ig, taur);
+  V<G> taur;
+  const V<G> taug = sw_taug<BAND, G>(T, s, (l + 1) <= c.laytrop, c.ig0, taur);
   double taua = 0.0, omga = 1.0, asya = 0.0;
-  if (d.tauaer) {
-    const long o = ((long)c.b * L + l) * N + col;
-    taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o];
-  }
-  // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
-  double ztauc = taur + taug + taua;
-  double zomcc = taur * 1.0 + taua * omga;
-  double zgcc = qdiv(asya * omga * taua, zomcc);
-  zomcc = qdiv(zomcc, ztauc);
-  {
-    const double zf = zgcc * zgcc, zwf = zomcc * zf;
-    ztauc = (1.0 - zwf) * ztauc;
-    zomcc = qdiv(zomcc - zwf, 1.0 - zwf);
-    zgcc = qdiv(zgcc - zf, 1.0 - zf);
-  }
-  sw_reftra(exp_tbl, zgcc, prmu0, ztauc, zomcc, clr.ref, clr.refd, clr.tra, clr.trad);
-  clr.dbt = sw_dbt(exp_tbl, ztauc, prmu0);
-  if (!c.cloudy_col) return;
-  tot = clr;
-  bool lcld;
-  double zcloud;
-  if (d.mcica) { lcld = mask_bit(c.mw, l); zcloud = lcld ? 1.0 : 0.0; }
-  else { zcloud = d.cldfr[i]; lcld = zcloud > 1.e-12; }
   const long o = ((long)c.b * L + l) * N + col;
-  const double ptauc = (lcld || !d.mcica) ? d.ctau[o] : 0.0;
-  if (lcld) {
-    const double pomgc = d.cssa[o], pasyc = d.casm[o];
-    // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
-    const double ztauo = ztauc + ptauc;
-    double zomco = ztauc * zomcc + ptauc * pomgc;
-    const double zgco = qdiv(ptauc * pomgc * pasyc + ztauc * zomcc * zgcc, zomco);
-    zomco = qdiv(zomco, ztauo);
-    double refo, refdo, trao, trado;
-    sw_reftra(exp_tbl, zgco, prmu0, ztauo, zomco, refo, refdo, trao, trado);
-    const double dbto = sw_dbt(exp_tbl, ztauo, prmu0);
-    if (d.mcica) {
-      tot.ref = refo; tot.refd = refdo; tot.tra = trao; tot.trad = trado; tot.dbt = dbto;
+  if (d.tauaer) { taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o]; }
+  // band cloud optics of this layer (shared by the g-points)
+  double zcloud = 0.0, ptauc = 0.0, pomgc = 0.0, pasyc = 0.0;
+  bool lcld_band = false;
+  if (c.any_cloudy) {
+    if (!d.mcica) { zcloud = d.cldfr[i]; lcld_band = zcloud > 1.e-12; }
+    ptauc = d.ctau[o];
+    pomgc = d.cssa[o]; pasyc = d.casm[o];
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
+    double ztauc, zomcc, zgcc;
+    if (d.tauaer) {
+      ztauc = taur[g] + taug[g] + taua;
+      zomcc = taur[g] * 1.0 + taua * omga;
+      zgcc = qdiv(asya * omga * taua, zomcc);
+      zomcc = qdiv(zomcc, ztauc);
+      const double zf = zgcc * zgcc, zwf = zomcc * zf;
+      ztauc = (1.0 - zwf) * ztauc;
+      zomcc = qdiv(zomcc - zwf, 1.0 - zwf);
+      zgcc = qdiv(zgcc - zf, 1.0 - zf);
+      sw_reftra<false>(exp_tbl, zgcc, prmu0, rmu0, ztauc, zomcc, clr[g].ref, clr[g].refd, clr[g].tra, clr[g].trad);
     } else {
-      const double zclear = 1.0 - zcloud;
-      tot.ref = zclear * clr.ref + zcloud * refo; tot.refd = zclear * clr.refd + zcloud * refdo;
-      tot.tra = zclear * clr.tra + zcloud * trao; tot.trad = zclear * clr.trad + zcloud * trado;
-      tot.dbt = zclear * clr.dbt + zcloud * dbto;
+      // no aerosol: taua = 0, omga = 1, asya = 0 -> zgcc = 0 and the delta scaling is the identity
+      ztauc = taur[g] + taug[g];
+      zomcc = qdiv(taur[g], ztauc);
+      zgcc = 0.0;
+      sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, clr[g].ref, clr[g].refd, clr[g].tra, clr[g].trad);
     }
-  } else if (!d.mcica && zcloud != 0.0) {
-    // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
-    const double zclear = 1.0 - zcloud;
-    const double dbto = sw_dbt(exp_tbl, ztauc + ptauc, prmu0);
-    tot.ref = zclear * clr.ref; tot.refd = zclear * clr.refd; tot.tra = zclear * clr.tra + zcloud; tot.trad = zclear * clr.trad + zcloud;
-    tot.dbt = zclear * clr.dbt + zcloud * dbto;
+    clr[g].dbt = sw_dbt(exp_tbl, ztauc, rmu0);
+    if (!c.cloudy[g]) continue;
+    tot[g] = clr[g];
+    bool lcld;
+    double zc;
+    if (d.mcica) { lcld = sw_mask_bit(d, c.iw0 + g, col, l); zc = lcld ? 1.0 : 0.0; }
+    else { zc = zcloud; lcld = lcld_band; }
+    const double ptc = (lcld || !d.mcica) ? ptauc : 0.0;
+    if (lcld) {
+      // icpr = 1 branch (rrtmg_sw_spcvrt.f90:503-509)
+      const double ztauo = ztauc + ptc;
+      double zomco = ztauc * zomcc + ptc * pomgc;
+      const double zgco = qdiv(ptc * pomgc * pasyc + ztauc * zomcc * zgcc, zomco);
+      zomco = qdiv(zomco, ztauo);
+      double refo, refdo, trao, trado;
+      sw_reftra<false>(exp_tbl, zgco, prmu0, rmu0, ztauo, zomco, refo, refdo, trao, trado);
+      const double dbto = sw_dbt(exp_tbl, ztauo, rmu0);
+      if (d.mcica) {
+        tot[g].ref = refo; tot[g].refd = refdo; tot[g].tra = trao; tot[g].trad = trado; tot[g].dbt = dbto;
+      } else {
+        const double zclear = 1.0 - zc;
+        tot[g].ref = zclear * clr[g].ref + zc * refo; tot[g].refd = zclear * clr[g].refd + zc * refdo;
+        tot[g].tra = zclear * clr[g].tra + zc * trao; tot[g].trad = zclear * clr[g].trad + zc * trado;
+        tot[g].dbt = zclear * clr[g].dbt + zc * dbto;
+      }
+    } else if (!d.mcica && zc != 0.0) {
+      // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
+      const double zclear = 1.0 - zc;
+      const double dbto = sw_dbt(exp_tbl, ztauc + ptc, rmu0);
+      tot[g].ref = zclear * clr[g].ref; tot[g].refd = zclear * clr[g].refd; tot[g].tra = zclear * clr[g].tra + zc;
+      tot[g].trad = zclear * clr[g].trad + zc;
+      tot[g].dbt = zclear * clr[g].dbt + zc * dbto;
+    }
   }
 }
 
-// One (column, g-point): both sweeps.  scr -> this thread's element of a [layer][field][stride] slab holding the
-// upward-sweep results (rup, rupd) for the clear and -- in cloudy columns -- the total sky.
-template <int BAND, class Sink>
-RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, int col, int ig, double *scr, long stride, Sink &sink) {
+// One (column, work item): both sweeps for the item's G g-points.  scr -> this thread's element of a
+// [layer][field][G][stride] slab holding the upward-sweep results (rup, rupd) for the clear and -- in cloudy
+// (sub-)columns -- the total sky.  The weighted fluxes of the G g-points are added in g-point order before they
+// leave through `sink`.
+template <int BAND, int G, class Sink>
+RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_tbl, int col, int ig0, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
-  SwThreadCtx c;
+  SwThreadCtx<G> c;
+  c.exp_tbl = exp_tbl;
   c.b = BAND - 16;
-  c.ig = ig;
-  c.iw = T.b[c.b].gs + ig;
+  c.ig0 = ig0;
+  c.iw0 = T.b[c.b].gs + ig0;
   c.prmu0 = d.cossza[col];
+  c.rmu0 = 1.0 / c.prmu0;
   c.laytrop = d.laytrop[col];
-  const double zinc = sw_incflux<BAND>(d, T, col, ig, c.prmu0);
+  double zinc[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) zinc[g] = sw_incflux<BAND>(d, T, col, ig0 + g, c.prmu0);
   // albedo by band: bands 1-9 and 14 near-IR, 10-13 UV/vis (rrtmg_sw_rad.nomcica.f90:648-659)
   const bool vis = (c.b >= 9 && c.b <= 12);
   const double albp = vis ? d.asdir[col] : d.aldir[col];
   const double albd = vis ? d.asdif[col] : d.aldif[col];
-  c.cloudy_col = false;
-  c.mw[0] = c.mw[1] = c.mw[2] = c.mw[3] = 0;
-  if (d.icld >= 1) {
-    if (d.mcica) {
-      // fully unrolled (static indices keep the mask words in registers)
+  c.any_cloudy = false;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) if (w < d.nw) { c.mw[w] = d.mask[((long)c.iw * d.nw + w) * N + col]; c.cloudy_col |= (c.mw[w] != 0); }
-    } else {
-      c.cloudy_col = d.anycld[col] != 0;
+  for (int g = 0; g < G; ++g) {
+    c.cloudy[g] = false;
+    if (d.icld >= 1) {
+      if (d.mcica) {
+        for (int w = 0; w < d.nw; ++w) c.cloudy[g] |= (d.mask[((long)(c.iw0 + g) * d.nw + w) * N + col] != 0);
+      } else {
+        c.cloudy[g] = d.anycld[col] != 0;
+      }
     }
+    c.any_cloudy |= c.cloudy[g];
   }
-  auto S = [&](int f, int l) -> double & { return scr[((long)l * F_NTOT + f) * stride]; };
+#ifdef RRTMG_ABL_NOSCRATCH
+  auto S = [&](int f, int l, int g) -> double & { (void)l; return scr[(((long)0 * F_NTOT + f) * G + g) * stride]; };
+#else
+  auto S = [&](int f, int l, int g) -> double & { return scr[(((long)l * F_NTOT + f) * G + g) * stride]; };
+#endif
 
   // ---- sweep 1: bottom -> top, upward adding recurrence (rrtmg_sw_vrtqdr.f90:114-140) ---------------
-  double rupc = albp, rupdc = albd, rup = albp, rupd = albd;
+  double rupc[G], rupdc[G], rup[G], rupd[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { rupc[g] = albp; rupdc[g] = albd; rup[g] = albp; rupd[g] = albd; }
   for (int l = 0; l < L; ++l) {
-    SwLayerOpt oc, ot;
-    sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
-    {
-      const double zr = qrcp(1.0 - rupdc * oc.refd);
-      const double nrup = oc.ref + (oc.trad * ((oc.tra - oc.dbt) * rupdc + oc.dbt * rupc)) * zr;
-      const double nrupd = oc.refd + oc.trad * oc.trad * rupdc * zr;
-      rupc = nrup; rupdc = nrupd;
-    }
-    S(F_RUP, l) = rupc; S(F_RUPD, l) = rupdc;
-    if (c.cloudy_col) {
-      const double zr = qrcp(1.0 - rupd * ot.refd);
-      const double nrup = ot.ref + (ot.trad * ((ot.tra - ot.dbt) * rupd + ot.dbt * rup)) * zr;
-      const double nrupd = ot.refd + ot.trad * ot.trad * rupd * zr;
-      rup = nrup; rupd = nrupd;
-      S(F_NCLR + F_RUP, l) = rup; S(F_NCLR + F_RUPD, l) = rupd;
+    SwLayerOpt oc[G], ot[G];
+    sw_layer_optics<BAND, G>(d, T, c, col, l, oc, ot);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      {
+        const double zr = qrcp(1.0 - rupdc[g] * oc[g].refd);
+        const double nrup = oc[g].ref + (oc[g].trad * ((oc[g].tra - oc[g].dbt) * rupdc[g] + oc[g].dbt * rupc[g])) * zr;
+        const double nrupd = oc[g].refd + oc[g].trad * oc[g].trad * rupdc[g] * zr;
+        rupc[g] = nrup; rupdc[g] = nrupd;
+      }
+      S(F_RUP, l, g) = rupc[g]; S(F_RUPD, l, g) = rupdc[g];
+      if (c.cloudy[g]) {
+        const double zr = qrcp(1.0 - rupd[g] * ot[g].refd);
+        const double nrup = ot[g].ref + (ot[g].trad * ((ot[g].tra - ot[g].dbt) * rupd[g] + ot[g].dbt * rup[g])) * zr;
+        const double nrupd = ot[g].refd + ot[g].trad * ot[g].trad * rupd[g] * zr;
+        rup[g] = nrup; rupd[g] = nrupd;
+        S(F_NCLR + F_RUP, l, g) = rup[g]; S(F_NCLR + F_RUPD, l, g) = rupd[g];
+      }
     }
   }
 
   // ---- sweep 2: top -> bottom; downward recurrence + fluxes at every interface (:142-169) -------------
-  double tdnc = 1.0, rdndc = 0.0, tdbtc = 1.0, tdn = 1.0, rdnd = 0.0, tdbt = 1.0;
+  double tdnc[G], rdndc[G], tdbtc[G], tdn[G], rdnd[G], tdbt[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { tdnc[g] = 1.0; rdndc[g] = 0.0; tdbtc[g] = 1.0; tdn[g] = 1.0; rdnd[g] = 0.0; tdbt[g] = 1.0; }
   for (int lev = L; lev >= 0; --lev) {
-    const double rc = (lev > 0) ? S(F_RUP, lev - 1) : albp;
-    const double rdc = (lev > 0) ? S(F_RUPD, lev - 1) : albd;
-    double zr = qrcp(1.0 - rdndc * rdc);
-    const double cu = (tdbtc * rc + (tdnc - tdbtc) * rdc) * zr;
-    const double cd = tdbtc + (tdnc - tdbtc + tdbtc * rc * rdndc) * zr;
-    double fu = cu, fd = cd;
-    if (c.cloudy_col) {
-      const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1) : albp;
-      const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1) : albd;
-      zr = qrcp(1.0 - rdnd * rd);
-      fu = (tdbt * r + (tdn - tdbt) * rd) * zr;
-      fd = tdbt + (tdn - tdbt + tdbt * r * rdnd) * zr;
+    double sfu = 0.0, sfd = 0.0, scu = 0.0, scd = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double rc = (lev > 0) ? S(F_RUP, lev - 1, g) : albp;
+      const double rdc = (lev > 0) ? S(F_RUPD, lev - 1, g) : albd;
+      double zr = qrcp(1.0 - rdndc[g] * rdc);
+      const double cu = (tdbtc[g] * rc + (tdnc[g] - tdbtc[g]) * rdc) * zr;
+      const double cd = tdbtc[g] + (tdnc[g] - tdbtc[g] + tdbtc[g] * rc * rdndc[g]) * zr;
+      double fu = cu, fd = cd;
+      if (c.cloudy[g]) {
+        const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1, g) : albp;
+        const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1, g) : albd;
+        zr = qrcp(1.0 - rdnd[g] * rd);
+        fu = (tdbt[g] * r + (tdn[g] - tdbt[g]) * rd) * zr;
+        fd = tdbt[g] + (tdn[g] - tdbt[g] + tdbt[g] * r * rdnd[g]) * zr;
+      }
+      sfu = sfu + zinc[g] * fu; sfd = sfd + zinc[g] * fd; scu = scu + zinc[g] * cu; scd = scd + zinc[g] * cd;
     }
-    sink.emit(lev, zinc * fu, zinc * fd, zinc * cu, zinc * cd);
+#ifdef RRTMG_ABL_NOSINK
+    if (sfu == 123.456) sink.emit(lev, sfu, sfd, scu, scd);
+#else
+    sink.emit(lev, sfu, sfd, scu, scd);
+#endif
     if (lev > 0) {
       const int l = lev - 1;
-      SwLayerOpt oc, ot;
-      sw_layer_optics<BAND>(d, T, c, col, l, oc, ot);
-      {
-        zr = qrcp(1.0 - oc.refd * rdndc);
-        const double ntdn = tdbtc * oc.tra + (oc.trad * ((tdnc - tdbtc) + tdbtc * oc.ref * rdndc)) * zr;
-        const double nrdnd = oc.refd + oc.trad * oc.trad * rdndc * zr;
-        tdnc = ntdn; rdndc = nrdnd; tdbtc = oc.dbt * tdbtc;
-      }
-      if (c.cloudy_col) {
-        zr = qrcp(1.0 - ot.refd * rdnd);
-        const double ntdn = tdbt * ot.tra + (ot.trad * ((tdn - tdbt) + tdbt * ot.ref * rdnd)) * zr;
-        const double nrdnd = ot.refd + ot.trad * ot.trad * rdnd * zr;
-        tdn = ntdn; rdnd = nrdnd; tdbt = ot.dbt * tdbt;
+      SwLayerOpt oc[G], ot[G];
+#ifdef RRTMG_ABL_NORECOMPUTE
+#pragma unroll
+      for (int g = 0; g < G; ++g) { oc[g].ref = 0.1 + 1e-3 * l; oc[g].refd = 0.1; oc[g].tra = 0.8; oc[g].trad = 0.8; oc[g].dbt = 0.7; ot[g] = oc[g]; }
+#else
+      sw_layer_optics<BAND, G>(d, T, c, col, l, oc, ot);
+#endif
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        {
+          const double zr = qrcp(1.0 - oc[g].refd * rdndc[g]);
+          const double ntdn = tdbtc[g] * oc[g].tra + (oc[g].trad * ((tdnc[g] - tdbtc[g]) + tdbtc[g] * oc[g].ref * rdndc[g])) * zr;
+          const double nrdnd = oc[g].refd + oc[g].trad * oc[g].trad * rdndc[g] * zr;
+          tdnc[g] = ntdn; rdndc[g] = nrdnd; tdbtc[g] = oc[g].dbt * tdbtc[g];
+        }
+        if (c.cloudy[g]) {
+          const double zr = qrcp(1.0 - ot[g].refd * rdnd[g]);
+          const double ntdn = tdbt[g] * ot[g].tra + (ot[g].trad * ((tdn[g] - tdbt[g]) + tdbt[g] * ot[g].ref * rdnd[g])) * zr;
+          const double nrdnd = ot[g].refd + ot[g].trad * ot[g].trad * rdnd[g] * zr;
+          tdn[g] = ntdn; rdnd[g] = nrdnd; tdbt[g] = ot[g].dbt * tdbt[g];
+        }
       }
     }
+  }
+}
+
+// Dispatch of one work item (packed, see SwTab) for one column: band switch + G in {4, 2}.
+template <int BAND, class Sink>
+RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
+  constexpr int ng = SwBandCfg<BAND>::ng;
+  if constexpr (ng >= 4 && RRTMG_GMAX >= 4) {
+    if (g == 4) { sw_solve_thread<BAND, 4>(d, T, exp_tbl, col, ig0, scr, stride, sink); return; }
+  }
+  if constexpr (ng % 4 != 0 || RRTMG_GMAX < 4) sw_solve_thread<BAND, 2>(d, T, exp_tbl, col, ig0, scr, stride, sink);
+}
+template <class Sink>
+RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tbl, int item, int col, double *scr, long stride, Sink &sink) {
+  const int g = item_g(item), ig0 = item_ig0(item);
+  switch (item_band(item) + 16) {
+    case 16: sw_solve_band<16>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 17: sw_solve_band<17>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 18: sw_solve_band<18>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 19: sw_solve_band<19>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 20: sw_solve_band<20>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 21: sw_solve_band<21>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 22: sw_solve_band<22>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 23: sw_solve_band<23>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 24: sw_solve_band<24>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 25: sw_solve_band<25>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 26: sw_solve_band<26>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 27: sw_solve_band<27>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 28: sw_solve_band<28>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    default: sw_solve_band<29>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
   }
 }
 
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
 // one thread per (column, interface level): g-point sum in reference order
-// nparts = 112 (per-g-point partials, host emulation) or 28 (block-reduced partials of the device kernel)
+// nparts = number of work items (T.nitem); each partial already holds the sum over its item's g-points
 RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev, int nparts) {
   const int L = d.nlay, N = d.ncol;
   double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;

@@ -3,6 +3,7 @@
 #pragma once
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "rrtmg_sw_device.h"
 #include "rrtmg_tables.h"
@@ -19,15 +20,28 @@ inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
     if (o < 0 && required) err = "reduced table '" + n + "' missing";
     return o < 0 ? 0 : o;
   };
+  const int kNg[kSwNBand] = {SwBandCfg<16>::ng, SwBandCfg<17>::ng, SwBandCfg<18>::ng, SwBandCfg<19>::ng, SwBandCfg<20>::ng,
+                             SwBandCfg<21>::ng, SwBandCfg<22>::ng, SwBandCfg<23>::ng, SwBandCfg<24>::ng, SwBandCfg<25>::ng,
+                             SwBandCfg<26>::ng, SwBandCfg<27>::ng, SwBandCfg<28>::ng, SwBandCfg<29>::ng};
   for (int b = 0; b < kSwNBand; ++b) {
     SwBandTab &B = T.b[b];
     const std::string p = "sw/kg" + std::to_string(16 + b) + "/";
     B.ng = (*ngc)[b];
     B.gs = b == 0 ? 0 : (*ngs)[b - 1];
-    B.absa = off(p + "absa", false); B.absb = off(p + "absb", false);
-    B.self = off(p + "selfref", false); B.forr = off(p + "forref", false);
+    if (B.ng != kNg[b]) { err = "reduced g-point count of band " + std::to_string(16 + b) + " differs from the compiled-in one"; return false; }
     B.nfor = 4;
     { auto it = ts.reg.find(p + "forref"); if (it != ts.reg.end()) B.nfor = (int)it->second.dims[0]; }
+    // g-point-fastest copies ([row][ng]) of the per-g-point tables ([ng][row]) for the vector loads of the kernel
+    auto gfast = [&](const std::string &n) -> long {
+      auto it = ts.reg.find(p + n);
+      if (it == ts.reg.end()) return 0;
+      const long o = it->second.off, rows = it->second.n / B.ng;
+      std::vector<double> tr((size_t)it->second.n);
+      for (int ig = 0; ig < B.ng; ++ig)
+        for (long r = 0; r < rows; ++r) tr[(size_t)r * B.ng + ig] = ts.flat[(size_t)o + (size_t)ig * rows + r];
+      return ts.add(p + n + "_g", tr.data(), (long)tr.size(), {(uint32_t)rows, (uint32_t)B.ng});
+    };
+    B.absa = gfast("absa"); B.absb = gfast("absb"); B.self = gfast("selfref"); B.forr = gfast("forref");
     B.sflux = off(p + "sfluxref", true); B.irr = off(p + "irradnce", true);
     B.fac = off(p + "facbrght", true); B.sns = off(p + "snsptdrk", true);
     { auto it = ts.reg.find(p + "sfluxref"); B.nsrc = it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
@@ -61,6 +75,24 @@ inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
   T.wavenum2 = off("sw/wvn/wavenum2", true);
   T.rsrtaua = off("sw/aer/rsrtaua", true); T.rsrpiza = off("sw/aer/rsrpiza", true); T.rsrasya = off("sw/aer/rsrasya", true);
   T.heatfac = ts.heatfac;
+  // work items: chunks of 4 (then 2) consecutive g-points of a band; launch order heaviest first
+  T.nitem = 0;
+  double cost[kSwMaxItem];
+  const int nspa[kSwNBand] = {9, 9, 9, 9, 1, 9, 9, 1, 9, 1, 0, 1, 9, 1};
+  for (int b = 0; b < kSwNBand; ++b) {
+    int ig = 0;
+    while (ig < T.b[b].ng) {
+      const int g = (T.b[b].ng - ig >= 4 && RRTMG_GMAX >= 4) ? 4 : 2;
+      if (T.nitem >= kSwMaxItem) { err = "too many work items"; return false; }
+      cost[T.nitem] = (nspa[b] == 9 ? 1.0 : 0.6) + g * 1.0;
+      T.item[T.nitem] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);
+      T.sched[T.nitem] = T.nitem;
+      ++T.nitem;
+      ig += g;
+    }
+  }
+  for (int i = 1; i < T.nitem; ++i)   // stable insertion sort, descending cost
+    for (int j = i; j > 0 && cost[T.sched[j]] > cost[T.sched[j - 1]]; --j) { const int t = T.sched[j]; T.sched[j] = T.sched[j - 1]; T.sched[j - 1] = t; }
   return err.empty();
 }
 

@@ -20,14 +20,12 @@ namespace rrtmg {
 void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
 }
 
-template <int BAND>
 static void emu_solve(const SwDev &d, const SwTab &T) {
-  const int ng = T.b[BAND - 16].ng;
-  std::vector<double> scr((size_t)F_NTOT * d.nlay);
-  for (int ig = 0; ig < ng; ++ig)
+  std::vector<double> scr((size_t)F_NTOT * d.nlay * 4);
+  for (int slot = 0; slot < T.nitem; ++slot)
     for (int col = 0; col < d.ncol; ++col) {
-      SwPartSink sink = sw_part_sink(d, T.b[BAND - 16].gs + ig, col);
-      sw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1, sink);
+      SwPartSink sink = sw_part_sink(d, slot, col);
+      sw_solve_item(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
     }
 }
 
@@ -108,10 +106,8 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
       }
     }
   }
-  emu_solve<16>(d, T); emu_solve<17>(d, T); emu_solve<18>(d, T); emu_solve<19>(d, T); emu_solve<20>(d, T);
-  emu_solve<21>(d, T); emu_solve<22>(d, T); emu_solve<23>(d, T); emu_solve<24>(d, T); emu_solve<25>(d, T);
-  emu_solve<26>(d, T); emu_solve<27>(d, T); emu_solve<28>(d, T); emu_solve<29>(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, kSwNGpt);
+  emu_solve(d, T);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, T.nitem);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) sw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
