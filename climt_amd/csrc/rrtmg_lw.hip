@@ -5,7 +5,7 @@
 //   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
-//   lw_solve_all_kernel  one launch: grid = tiles(64 columns) x 35 g-groups (XCD-aware), block = 4 wavefronts
+//   lw_solve_all_kernel  one launch: grid = tiles(64 columns) x work items (4|2 g-points of a band), block = 1 wavefront
 //   lw_flux_kernel       <<<ncol/64, nlay+1>>>  band / g-point integration per interface
 //   lw_heat_kernel       <<<ncol/64, nlay>>>    heating rates
 #include "rrtmg_ctx.h"
@@ -31,97 +31,31 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_anymask_column(d, col);
 }
-// All 140 g-points in ONE launch; same (tile, g-group) -> XCD mapping as the shortwave (rrtmg_sw.hip).
-constexpr int kLwGroup = 4;
 
-// Block-reducing radiance sink (see SwBlockSink): the 4 wavefronts of a block add their band-weighted radiances
-// through LDS; wave k reduces quantity k.  One __syncthreads per emit, double-buffered by call parity.
-struct LwBlockSink {
-  double (*sh)[kLwGroup][4][64];
-  double *p;     // part + (grp*nk*(L+1))*N + col
-  long N, st;
-  int wave, lane, phase;
-  bool idrv;
-  __device__ void reduce_store(int k, int slot, int lev) {
-    double s = sh[phase][0][slot][lane];
-    s = s + sh[phase][1][slot][lane]; s = s + sh[phase][2][slot][lane]; s = s + sh[phase][3][slot][lane];
-    p[k * st + (long)lev * N] = s;
-  }
-  __device__ void dn(int lev, double rd, double rcd) {
-    sh[phase][wave][0][lane] = rd; sh[phase][wave][1][lane] = rcd;
-#ifndef RRTMG_EXP_NOSYNC
-    __syncthreads();
-#endif
-    if (wave == 0) reduce_store(1, 0, lev);
-    if (wave == 1) reduce_store(3, 1, lev);
-    phase ^= 1;
-  }
-  __device__ void up(int lev, double ru, double rcu, double du, double dcu) {
-    sh[phase][wave][0][lane] = ru; sh[phase][wave][1][lane] = rcu;
-    if (idrv) { sh[phase][wave][2][lane] = du; sh[phase][wave][3][lane] = dcu; }
-#ifndef RRTMG_EXP_NOSYNC
-    __syncthreads();
-#endif
-    if (wave == 0) reduce_store(0, 0, lev);
-    if (wave == 1) reduce_store(2, 1, lev);
-    if (idrv && wave == 2) reduce_store(4, 2, lev);
-    if (idrv && wave == 3) reduce_store(5, 3, lev);
-    phase ^= 1;
-  }
-};
-
+// All 140 g-points in ONE launch.  Block = one wavefront = 64 columns of one tile x one work item (4 or 2
+// consecutive g-points of a band, LwTab::item).  The thread carries the item's g-points through both sweeps: the
+// layer state, the species mixtures (specparm/js/fs of the major, minor and Planck mixtures, adjusted columns),
+// the Planck functions and the cloud optics -- more than half of the per-g-point work of rtrnmc+taumol -- are
+// evaluated once per item, and every table row is one 16/32-byte load.  The item's band-weighted radiances are
+// summed in registers: part[item][k][level][column].  Launch order: items heaviest first (LwTab::sched), tiles
+// fastest (a tile count that is a multiple of 8 keeps a tile on one XCD).  Speed only, never correctness.
 #ifndef RRTMG_LW_WAVES
 #define RRTMG_LW_WAVES 3
 #endif
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile8, int tile_order) {
-  __shared__ double sh[2][kLwGroup][4][64];
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile) {
   const int q = blockIdx.x;
-  const int xcd = q & 7, r = q >> 3;
-  const int ngrp = kLwNGpt / kLwGroup;
-  const int nt = ntile8 >> 3;   // tiles per XCD
-  const int grp = tile_order ? r / nt : r % ngrp;
-  const int tile = (tile_order ? r % nt : r / ngrp) * 8 + xcd;
+  const int tile = q % ntile, k = q / ntile;
+  const int slot = T.sched[k], item = T.item[slot];
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  // wavefront index as a SCALAR: g-point, band and every table offset derived from them stay in SGPRs and the
-  // band switch is a scalar branch
-#ifdef RRTMG_EXP_NOSCALAR
-  const int wave = threadIdx.y;
-#else
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.y);
-#endif
-  const int iw = grp * kLwGroup + wave;
-  int b = 0;
-  while (b < kLwNBand - 1 && iw >= T.b[b].gs + T.b[b].ng) ++b;
-  const int ig = iw - T.b[b].gs;
-  double *scr = d.scratch + ((long)tile * kLwNGpt + iw) * (long)LF_N * d.nlay * 64 + threadIdx.x;
-  LwBlockSink sink;
-  sink.sh = sh; sink.N = d.ncol; sink.st = (long)(d.nlay + 1) * d.ncol; sink.wave = wave; sink.lane = threadIdx.x;
-  sink.phase = 0; sink.idrv = d.idrv != 0;
-  sink.p = d.part + ((long)grp * (d.idrv ? 6 : 4) * (d.nlay + 1)) * d.ncol + col;
-  switch (b + 1) {
-    case 1: lw_solve_thread<1>(d, T, col, ig, scr, 64, sink); break;
-    case 2: lw_solve_thread<2>(d, T, col, ig, scr, 64, sink); break;
-    case 3: lw_solve_thread<3>(d, T, col, ig, scr, 64, sink); break;
-    case 4: lw_solve_thread<4>(d, T, col, ig, scr, 64, sink); break;
-    case 5: lw_solve_thread<5>(d, T, col, ig, scr, 64, sink); break;
-    case 6: lw_solve_thread<6>(d, T, col, ig, scr, 64, sink); break;
-    case 7: lw_solve_thread<7>(d, T, col, ig, scr, 64, sink); break;
-    case 8: lw_solve_thread<8>(d, T, col, ig, scr, 64, sink); break;
-    case 9: lw_solve_thread<9>(d, T, col, ig, scr, 64, sink); break;
-    case 10: lw_solve_thread<10>(d, T, col, ig, scr, 64, sink); break;
-    case 11: lw_solve_thread<11>(d, T, col, ig, scr, 64, sink); break;
-    case 12: lw_solve_thread<12>(d, T, col, ig, scr, 64, sink); break;
-    case 13: lw_solve_thread<13>(d, T, col, ig, scr, 64, sink); break;
-    case 14: lw_solve_thread<14>(d, T, col, ig, scr, 64, sink); break;
-    case 15: lw_solve_thread<15>(d, T, col, ig, scr, 64, sink); break;
-    default: lw_solve_thread<16>(d, T, col, ig, scr, 64, sink); break;
-  }
+  double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x;
+  LwPartSink sink = lw_part_sink(d, slot, col);
+  lw_solve_item(d, T, item, col, scr, 64, sink);
 }
 
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, kLwNGpt / kLwGroup);
+  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem);
 }
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -222,7 +156,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const int ntile = (N + 63) / 64;
   const int nk = d.idrv ? 6 : 4;
   d.scratch = wd("scratch", (size_t)ntile * kLwNGpt * LF_N * L * 64);
-  d.part = wd("part", (size_t)(kLwNGpt / kLwGroup) * nk * nl1);
+  d.part = wd("part", (size_t)T.nitem * nk * nl1);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
   if (a->memspace == 1) {
@@ -262,13 +196,10 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
     }
   }
-  {
-    const int ntile8 = (ntile + 7) / 8 * 8;
-    (void)hipEventRecord(ctx->ev[1][0], s);
-    hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile8 * (kLwNGpt / kLwGroup)), dim3(64, kLwGroup), 0, s, d, T, ntile8, ctx->tile_order);
-    (void)hipEventRecord(ctx->ev[1][1], s);
-    ctx->ev_valid[1] = true;
-  }
+  (void)hipEventRecord(ctx->ev[1][0], s);
+  hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  (void)hipEventRecord(ctx->ev[1][1], s);
+  ctx->ev_valid[1] = true;
   hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
   hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());

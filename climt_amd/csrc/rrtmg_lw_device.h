@@ -25,15 +25,24 @@ constexpr int kLwNGpt = 140;
 struct LwBandTab {
   int ng, gs;
   int nfraca, nfracb;      // Planck-fraction mixtures (1, 9 / 1, 5)
-  long absa, absb, self, forr, fraca, fracb;
-  long ma[3];              // lower-atmosphere minor-gas tables
-  long mb[2];              // upper-atmosphere minor-gas tables
+  long absa, absb, self, forr, fraca, fracb;   // absa/absb/self/forr: g-point-fastest copies [row][ng]
+  long ma[3];              // lower-atmosphere minor-gas tables, g-point-fastest [19 * nm][ng]
+  long mb[2];              // upper-atmosphere minor-gas tables, g-point-fastest
   long x[2];               // cross-section tables (ccl4 | cfc11adj, cfc12 | cfc12, cfc22adj)
 };
+
+// work items of the solve kernel: see SwTab (packed band | ig0 << 8 | G << 16 | first g-point << 20)
+constexpr int kLwMaxItem = 72;
+#ifndef RRTMG_LW_GMAX
+#define RRTMG_LW_GMAX 4
+#endif
 
 struct LwTab {
   const double *t;
   LwBandTab b[kLwNBand];
+  int nitem;
+  int32_t item[kLwMaxItem], sched[kLwMaxItem];
+  long chirat;             // [CR_N][59] species ratios chi_mls(x, j)/chi_mls(y, j)
   long preflog, tref, chi_mls, totplnk, totplk16, totplnkderiv, totplk16deriv;
   long exp_tbl, tau_tbl, tfn_tbl, delwave;
   long abscld1, absice0, absice1, absice2, absice3, absliq0, absliq1;
@@ -61,7 +70,7 @@ struct LwDev {
   uint64_t *anymask;   // [nw][col]   OR over the sub-columns (icldlyr of rtrnmc)
   int nw;
   double *scratch;
-  double *part;        // [140][nk][nlay+1][col], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd
+  double *part;        // [item][nk][nlay+1][col], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd summed over the item
   int *err;
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
 };
@@ -393,55 +402,64 @@ RRTMG_HD LwSpec lw_spec(double colx, double rat, double coly, double mult) {
 RRTMG_HD double lw_chi(const LwTab &T, int m, int j) { return T.t[T.chi_mls + (m - 1) + 7 * (j - 1)]; }
 
 // lower-atmosphere binary-species major term with the 3-point end-zone blend
-// (pattern at rrtmg_lw_taumol.f90:550-609 / :622-668); k -> table of this g-point, ind 0-based index
+// (pattern at rrtmg_lw_taumol.f90:550-609 / :622-668); k -> g-point-fastest table view, ind 0-based row
 // of (js, jt, jp) ; f0/f1 = (fac00, fac10) for the jp side or (fac01, fac11) for the jp+1 side.
-RRTMG_HD double lw_major_lower(const double *k, int ind, const LwSpec &sp, double f0, double f1) {
+template <int G, int NG>
+RRTMG_HD V<G> lw_major_lower(const KTab<G, NG> &k, int ind, const LwSpec &sp, double f0, double f1) {
   if (sp.specparm < 0.125) {
     const double p = sp.fs - 1;
     const double p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-    return sp.speccomb * (fk0 * f0 * k[ind] + fk1 * f0 * k[ind + 1] + fk2 * f0 * k[ind + 2] + fk0 * f1 * k[ind + 9] +
-                          fk1 * f1 * k[ind + 10] + fk2 * f1 * k[ind + 11]);
+    return sp.speccomb * ((fk0 * f0) * k[ind] + (fk1 * f0) * k[ind + 1] + (fk2 * f0) * k[ind + 2] + (fk0 * f1) * k[ind + 9] +
+                          (fk1 * f1) * k[ind + 10] + (fk2 * f1) * k[ind + 11]);
   } else if (sp.specparm > 0.875) {
     const double p = -sp.fs;
     const double p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-    return sp.speccomb * (fk2 * f0 * k[ind - 1] + fk1 * f0 * k[ind] + fk0 * f0 * k[ind + 1] + fk2 * f1 * k[ind + 8] +
-                          fk1 * f1 * k[ind + 9] + fk0 * f1 * k[ind + 10]);
+    return sp.speccomb * ((fk2 * f0) * k[ind - 1] + (fk1 * f0) * k[ind] + (fk0 * f0) * k[ind + 1] + (fk2 * f1) * k[ind + 8] +
+                          (fk1 * f1) * k[ind + 9] + (fk0 * f1) * k[ind + 10]);
   }
-  return sp.speccomb * ((1.0 - sp.fs) * f0 * k[ind] + sp.fs * f0 * k[ind + 1] + (1.0 - sp.fs) * f1 * k[ind + 9] +
-                        sp.fs * f1 * k[ind + 10]);
+  return sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 9] +
+                        (sp.fs * f1) * k[ind + 10]);
 }
 // upper-atmosphere binary-species term (4 points, nspb = 5)
-RRTMG_HD double lw_major_upper(const double *k, int ind, const LwSpec &sp, double f0, double f1) {
-  return sp.speccomb * ((1.0 - sp.fs) * f0 * k[ind] + sp.fs * f0 * k[ind + 1] + (1.0 - sp.fs) * f1 * k[ind + 5] + sp.fs * f1 * k[ind + 6]);
+template <int G, int NG>
+RRTMG_HD V<G> lw_major_upper(const KTab<G, NG> &k, int ind, const LwSpec &sp, double f0, double f1) {
+  return sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 5] + (sp.fs * f1) * k[ind + 6]);
 }
-RRTMG_HD double lw_m4(const double *k, int i0, int i1, const LwLayerIn &s) {
+template <int G, int NG>
+RRTMG_HD V<G> lw_m4(const KTab<G, NG> &k, int i0, int i1, const LwLayerIn &s) {
   return s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1];
 }
-RRTMG_HD double lw_tauself(const double *selfref, const LwLayerIn &s) {
-  const double a = selfref[s.indself - 1], b = selfref[s.indself];
+template <int G, int NG>
+RRTMG_HD V<G> lw_tauself(const KTab<G, NG> &selfref, const LwLayerIn &s) {
+  const V<G> a = selfref[s.indself - 1], b = selfref[s.indself];
   return s.selffac * (a + s.selffrac * (b - a));
 }
-RRTMG_HD double lw_taufor(const double *forref, const LwLayerIn &s) {
-  const double a = forref[s.indfor - 1], b = forref[s.indfor];
+template <int G, int NG>
+RRTMG_HD V<G> lw_taufor(const KTab<G, NG> &forref, const LwLayerIn &s) {
+  const V<G> a = forref[s.indfor - 1], b = forref[s.indfor];
   return s.forfac * (a + s.forfrac * (b - a));
 }
-// minor-gas coefficient, temperature-interpolated: table (19, ng)
-RRTMG_HD double lw_minor1(const double *tab, int ig, const LwLayerIn &s) {
-  const double *m = tab + 19 * ig + (s.indminor - 1);
-  return m[0] + s.minorfrac * (m[1] - m[0]);
+// minor-gas coefficient, temperature-interpolated: table (19, ng) stored [19][ng]
+template <int G, int NG>
+RRTMG_HD V<G> lw_minor1(const KTab<G, NG> &m, const LwLayerIn &s) {
+  const V<G> a = m[s.indminor - 1], b = m[s.indminor];
+  return a + s.minorfrac * (b - a);
 }
-// minor-gas coefficient, (mixture, temperature)-interpolated: table (nm, 19, ng)
-RRTMG_HD double lw_minor2(const double *tab, int nm, int ig, int jm, double fm, const LwLayerIn &s) {
-  const double *m = tab + (long)nm * 19 * ig + (long)nm * (s.indminor - 1) + (jm - 1);
-  const double m1 = m[0] + fm * (m[1] - m[0]);
-  const double m2 = m[nm] + fm * (m[nm + 1] - m[nm]);
+// minor-gas coefficient, (mixture, temperature)-interpolated: table (nm, 19, ng) stored [19*nm][ng]
+template <int G, int NG>
+RRTMG_HD V<G> lw_minor2(const KTab<G, NG> &m, int nm, int jm, double fm, const LwLayerIn &s) {
+  const int r = nm * (s.indminor - 1) + (jm - 1);
+  const V<G> a0 = m[r], a1 = m[r + 1], b0 = m[r + nm], b1 = m[r + nm + 1];
+  const V<G> m1 = a0 + fm * (a1 - a0);
+  const V<G> m2 = b0 + fm * (b1 - b0);
   return m1 + s.minorfrac * (m2 - m1);
 }
-// Planck fraction interpolated in the reference mixture: table (ng, nmix)
-RRTMG_HD double lw_frac2(const double *tab, int ng, int ig, const LwSpec &pl) {
-  const double a = tab[ig + ng * (pl.js - 1)], b = tab[ig + ng * pl.js];
+// Planck fraction interpolated in the reference mixture: table (ng, nmix) = [nmix][ng]
+template <int G, int NG>
+RRTMG_HD V<G> lw_frac2(const KTab<G, NG> &tab, const LwSpec &pl) {
+  const V<G> a = tab[pl.js - 1], b = tab[pl.js];
   return a + pl.fs * (b - a);
 }
 // "too abundant" minor-gas column adjustment: adjfac = a + (rat - a)**e  
@@ -457,226 +475,232 @@ RRTMG_HD double lw_adjcol(double col, double coldry, double chiref, double e20, 
 
 constexpr double kE20f = (double)1.e20f;   // `1.e20` default-real literals at rrtmg_lw_taumol.f90:715,:1462,:1618
 
-// gas optical depth and Planck fraction of one (layer, g-point) of band BAND (1..16)
-template <int BAND>
-RRTMG_HD double lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig, double &fracs) {
+// reduced g-points per band (rrtmg_lw parrrtm.f90 ng1..ng16)
+constexpr int kLwNg[16] = {10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2};
+// species-ratio pairs of the binary bands, rows of the chi ratio table built at init (LwTab::chirat)
+enum { CR_12 = 0, CR_32, CR_13, CR_16, CR_14, CR_42, CR_N };
+
+// gas optical depths and Planck fractions of the G g-points ig0 .. ig0+G-1 of band BAND (1..16) in one layer
+template <int BAND, int G>
+RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V<G> &fracs) {
   const LwBandTab &B = T.b[BAND - 1];
   const double *t = T.t;
-  constexpr int nspa_[16] = {1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9};
-  constexpr int nspb_[16] = {1, 1, 5, 5, 5, 0, 1, 1, 1, 1, 1, 0, 0, 1, 0, 0};
-  constexpr int nspa = nspa_[BAND - 1], nspb = nspb_[BAND - 1];
-  const double *absa = t + B.absa + (long)ig * 65 * nspa;
+  constexpr int NG = kLwNg[BAND - 1];
+  // g-point-fastest table views ([row][ng], rows as in the reference's first dimensions)
+  const KTab<G, NG> absa{t + B.absa + ig0}, absb{t + B.absb + ig0}, selfref{t + B.self + ig0}, forref{t + B.forr + ig0};
+  const KTab<G, NG> ma0{t + B.ma[0] + ig0}, ma1{t + B.ma[1] + ig0}, ma2{t + B.ma[2] + ig0}, mb0{t + B.mb[0] + ig0}, mb1{t + B.mb[1] + ig0};
+  const KTab<G, NG> fraca{t + B.fraca + ig0}, fracb{t + B.fracb + ig0};
+  auto row = [&](long base) { return vload<G>(t + base + ig0); };   // a [ng] table
+  V<G> taug = vsplat<G>(0.0);
+  const int i0s = ((s.jp - 1) * 5 + (s.jt - 1)), i1s = (s.jp * 5 + (s.jt1 - 1));         // lower, nspa = 1
   // band 16 has a kb table but nspb(16) = 0 in lwdatinit, so the reference's index
   // ((jp-13)*5+(jt-1))*nspb(16) + 1 collapses to 1 for every upper layer (rrtmg_lw_taumol.f90 taugb16)
-  const double *absb = t + B.absb + (long)ig * 235 * (BAND == 16 ? 1 : nspb);
-  const double *selfref = t + B.self + (long)ig * 10;
-  const double *forref = t + B.forr + (long)ig * 4;
-  const int ng = B.ng;
-  double taug = 0.0;
-  const int i0s = ((s.jp - 1) * 5 + (s.jt - 1)), i1s = (s.jp * 5 + (s.jt1 - 1));         // lower, nspa = 1
   const int u0s = ((s.jp - 13) * 5 + (s.jt - 1)) * (BAND == 16 ? 0 : 1), u1s = ((s.jp - 12) * 5 + (s.jt1 - 1)) * (BAND == 16 ? 0 : 1);  // upper, nspb = 1
-  // species pair of the binary bands: x = key species 1, y = key species 2, rat = chi_x/chi_y at jp, jp+1
-  auto chirat = [&](int mx, int my, int j) { return lw_chi(T, mx, j) / lw_chi(T, my, j); };
+  // species pair of the binary bands: chi_x/chi_y at reference level j (quotients formed at init)
+  auto chirat = [&](int pair, int j) { return t[T.chirat + pair * 59 + (j - 1)]; };
+  (void)ma1; (void)ma2; (void)mb1; (void)fracb; (void)absb; (void)chirat; (void)u0s; (void)u1s;
 
   if constexpr (BAND == 1) {
     const double scalen2 = s.colbrd * s.scaleminorn2;
     if (lower) {
       double corradj = 1.;
       if (s.pavel < 250.0) corradj = 1.0 - 0.15 * (250.0 - s.pavel) / 154.4;
-      const double taun2 = scalen2 * lw_minor1(t + B.ma[0], ig, s);
+      const V<G> taun2 = scalen2 * lw_minor1(ma0, s);
       taug = corradj * (s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + taun2);
-      fracs = t[B.fraca + ig];
+      fracs = fraca[0];
     } else {
       const double corradj = 1.0 - 0.15 * (s.pavel / 95.6);
-      const double taun2 = scalen2 * lw_minor1(t + B.mb[0], ig, s);
+      const V<G> taun2 = scalen2 * lw_minor1(mb0, s);
       taug = corradj * (s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s) + taun2);
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 2) {
     if (lower) {
       const double corradj = 1.0 - .05 * (s.pavel - 100.0) / 900.0;
       taug = corradj * (s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s));
-      fracs = t[B.fraca + ig];
+      fracs = fraca[0];
     } else {
       taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s);
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 3) {
     // h2o/co2; minor n2o
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
-      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 3), s.colco2, 8.0), pl = lw_spec(s.colh2o, chirat(1, 2, 9), s.colco2, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_12, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_12, s.jp + 1), s.colco2, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(CR_12, 3), s.colco2, 8.0), pl = lw_spec(s.colh2o, chirat(CR_12, 9), s.colco2, 8.0);
       const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), 1.e20, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
-      const double absn2o = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      const V<G> absn2o = lw_minor2(ma0, 9, sm.js, sm.fs, s);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcoln2o * absn2o;
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 4.0);
-      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 13), s.colco2, 4.0), pl = lw_spec(s.colh2o, chirat(1, 2, 13), s.colco2, 4.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_12, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colh2o, chirat(CR_12, s.jp + 1), s.colco2, 4.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(CR_12, 13), s.colco2, 4.0), pl = lw_spec(s.colh2o, chirat(CR_12, 13), s.colco2, 4.0);
       const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), kE20f, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
-      const double absn2o = lw_minor2(t + B.mb[0], 5, ig, sm.js, sm.fs, s);
+      const V<G> absn2o = lw_minor2(mb0, 5, sm.js, sm.fs, s);
       taug = lw_major_upper(absb, u0s * 5 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_upper(absb, u1s * 5 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_taufor(forref, s) + adjcoln2o * absn2o;
-      fracs = lw_frac2(t + B.fracb, ng, ig, pl);
+      fracs = lw_frac2(fracb, pl);
     }
   } else if constexpr (BAND == 4 || BAND == 5) {
     // lower h2o/co2 ; upper o3/co2.  band 5: minor o3 (lower), ccl4 (both)
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
-      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 2, BAND == 4 ? 11 : 5), s.colco2, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_12, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_12, s.jp + 1), s.colco2, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(CR_12, BAND == 4 ? 11 : 5), s.colco2, 8.0);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s);
       if constexpr (BAND == 5) {
-        const LwSpec sm = lw_spec(s.colh2o, chirat(1, 2, 7), s.colco2, 8.0);
-        const double abso3 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
-        taug = taug + abso3 * s.colo3 + s.wx1 * t[B.x[0] + ig];
+        const LwSpec sm = lw_spec(s.colh2o, chirat(CR_12, 7), s.colco2, 8.0);
+        const V<G> abso3 = lw_minor2(ma0, 9, sm.js, sm.fs, s);
+        taug = taug + abso3 * s.colo3 + s.wx1 * row(B.x[0]);
       }
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      const LwSpec sp = lw_spec(s.colo3, chirat(3, 2, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colo3, chirat(3, 2, s.jp + 1), s.colco2, 4.0);
-      const LwSpec pl = lw_spec(s.colo3, chirat(3, 2, BAND == 4 ? 13 : 43), s.colco2, 4.0);
+      const LwSpec sp = lw_spec(s.colo3, chirat(CR_32, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colo3, chirat(CR_32, s.jp + 1), s.colco2, 4.0);
+      const LwSpec pl = lw_spec(s.colo3, chirat(CR_32, BAND == 4 ? 13 : 43), s.colco2, 4.0);
       taug = lw_major_upper(absb, u0s * 5 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_upper(absb, u1s * 5 + sp1.js - 1, sp1, s.fac01, s.fac11);
-      if constexpr (BAND == 5) taug = taug + s.wx1 * t[B.x[0] + ig];
-      fracs = lw_frac2(t + B.fracb, ng, ig, pl);
+      if constexpr (BAND == 5) taug = taug + s.wx1 * row(B.x[0]);
+      fracs = lw_frac2(fracb, pl);
       if constexpr (BAND == 4) {
         // empirical stratospheric scalings, default-real literals (rrtmg_lw_taumol.f90:1009-1015)
         const double sc[7] = {(double)0.92f, (double)0.88f, (double)1.07f, (double)1.1f, (double)0.99f, (double)0.88f, (double)0.943f};
-        if (ig >= 7) taug = taug * sc[ig - 7];
+#pragma unroll
+        for (int j = 0; j < G; ++j) if (ig0 + j >= 7) taug[j] = taug[j] * sc[ig0 + j - 7];
       }
     }
   } else if constexpr (BAND == 6) {
     if (lower) {
       const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), 1.e20, 3.0, 2.0, 0.77, lw_chi(T, 2, s.jp + 1));
-      const double absco2 = lw_minor1(t + B.ma[0], ig, s);
+      const V<G> absco2 = lw_minor1(ma0, s);
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 +
-             s.wx2 * t[B.x[0] + ig] + s.wx3 * t[B.x[1] + ig];
+             s.wx2 * row(B.x[0]) + s.wx3 * row(B.x[1]);
     } else {
-      taug = 0.0 + s.wx2 * t[B.x[0] + ig] + s.wx3 * t[B.x[1] + ig];
+      taug = 0.0 + s.wx2 * row(B.x[0]) + s.wx3 * row(B.x[1]);
     }
-    fracs = t[B.fraca + ig];
+    fracs = fraca[0];
   } else if constexpr (BAND == 7) {
     // lower h2o/o3, minor co2 ; upper o3, minor co2
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 3, s.jp), s.colo3, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 3, s.jp + 1), s.colo3, 8.0);
-      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 3, 3), s.colo3, 8.0), pl = lw_spec(s.colh2o, chirat(1, 3, 3), s.colo3, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_13, s.jp), s.colo3, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_13, s.jp + 1), s.colo3, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(CR_13, 3), s.colo3, 8.0), pl = lw_spec(s.colh2o, chirat(CR_13, 3), s.colo3, 8.0);
       const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), kE20f, 3.0, 3.0, 0.79, lw_chi(T, 2, s.jp + 1));
-      const double absco2 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      const V<G> absco2 = lw_minor2(ma0, 9, sm.js, sm.fs, s);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2;
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
       const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), kE20f, 3.0, 2.0, 0.79, lw_chi(T, 2, s.jp + 1));
-      const double absco2 = lw_minor1(t + B.mb[0], ig, s);
+      const V<G> absco2 = lw_minor1(mb0, s);
       taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2;
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
       const double sc[6] = {0.92, 0.88, 1.07, 1.1, 0.99, 0.855};   // rrtmg_lw_taumol.f90:1645-1650 (_rb literals)
-      if (ig >= 5 && ig <= 10) taug = taug * sc[ig - 5];
+#pragma unroll
+      for (int j = 0; j < G; ++j) if (ig0 + j >= 5 && ig0 + j <= 10) taug[j] = taug[j] * sc[ig0 + j - 5];
     }
   } else if constexpr (BAND == 8) {
     const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), 1.e20, 3.0, 2.0, 0.65, lw_chi(T, 2, s.jp + 1));
     if (lower) {
-      const double absco2 = lw_minor1(t + B.ma[0], ig, s), abso3 = lw_minor1(t + B.ma[1], ig, s), absn2o = lw_minor1(t + B.ma[2], ig, s);
+      const V<G> absco2 = lw_minor1(ma0, s), abso3 = lw_minor1(ma1, s), absn2o = lw_minor1(ma2, s);
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 + s.colo3 * abso3 +
-             s.coln2o * absn2o + s.wx3 * t[B.x[0] + ig] + s.wx4 * t[B.x[1] + ig];
-      fracs = t[B.fraca + ig];
+             s.coln2o * absn2o + s.wx3 * row(B.x[0]) + s.wx4 * row(B.x[1]);
+      fracs = fraca[0];
     } else {
-      const double absco2 = lw_minor1(t + B.mb[0], ig, s), absn2o = lw_minor1(t + B.mb[1], ig, s);
-      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2 + s.coln2o * absn2o + s.wx3 * t[B.x[0] + ig] + s.wx4 * t[B.x[1] + ig];
-      fracs = t[B.fracb + ig];
+      const V<G> absco2 = lw_minor1(mb0, s), absn2o = lw_minor1(mb1, s);
+      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2 + s.coln2o * absn2o + s.wx3 * row(B.x[0]) + s.wx4 * row(B.x[1]);
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 9) {
     const double adjcoln2o = lw_adjcol(s.coln2o, s.coldry, lw_chi(T, 4, s.jp + 1), 1.e20, 1.5, 0.5, 0.65, lw_chi(T, 4, s.jp + 1));
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 6, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 6, s.jp + 1), s.colch4, 8.0);
-      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 6, 3), s.colch4, 8.0), pl = lw_spec(s.colh2o, chirat(1, 6, 9), s.colch4, 8.0);
-      const double absn2o = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_16, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_16, s.jp + 1), s.colch4, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(CR_16, 3), s.colch4, 8.0), pl = lw_spec(s.colh2o, chirat(CR_16, 9), s.colch4, 8.0);
+      const V<G> absn2o = lw_minor2(ma0, 9, sm.js, sm.fs, s);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcoln2o * absn2o;
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      const double absn2o = lw_minor1(t + B.mb[0], ig, s);
+      const V<G> absn2o = lw_minor1(mb0, s);
       taug = s.colch4 * lw_m4(absb, u0s, u1s, s) + adjcoln2o * absn2o;
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 10) {
     if (lower) {
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s);
-      fracs = t[B.fraca + ig];
+      fracs = fraca[0];
     } else {
       taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s);
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 11) {
     const double scaleo2 = s.colo2 * s.scaleminor;
     if (lower) {
-      const double tauo2 = scaleo2 * lw_minor1(t + B.ma[0], ig, s);
+      const V<G> tauo2 = scaleo2 * lw_minor1(ma0, s);
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + tauo2;
-      fracs = t[B.fraca + ig];
+      fracs = fraca[0];
     } else {
-      const double tauo2 = scaleo2 * lw_minor1(t + B.mb[0], ig, s);
+      const V<G> tauo2 = scaleo2 * lw_minor1(mb0, s);
       taug = s.colh2o * lw_m4(absb, u0s, u1s, s) + lw_taufor(forref, s) + tauo2;
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 12) {
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 2, s.jp + 1), s.colco2, 8.0);
-      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 2, 10), s.colco2, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_12, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_12, s.jp + 1), s.colco2, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(CR_12, 10), s.colco2, 8.0);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s);
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      taug = 0.0; fracs = 0.0;
+      taug = vsplat<G>(0.0); fracs = vsplat<G>(0.0);
     }
   } else if constexpr (BAND == 13) {
     // lower h2o/n2o, minor co2 and co ; upper o3 minor only
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 4, s.jp), s.coln2o, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 4, s.jp + 1), s.coln2o, 8.0);
-      const LwSpec sm = lw_spec(s.colh2o, chirat(1, 4, 1), s.coln2o, 8.0), sm3 = lw_spec(s.colh2o, chirat(1, 4, 3), s.coln2o, 8.0);
-      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 4, 5), s.coln2o, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_14, s.jp), s.coln2o, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_14, s.jp + 1), s.coln2o, 8.0);
+      const LwSpec sm = lw_spec(s.colh2o, chirat(CR_14, 1), s.coln2o, 8.0), sm3 = lw_spec(s.colh2o, chirat(CR_14, 3), s.coln2o, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(CR_14, 5), s.coln2o, 8.0);
       // adjcolco2 = adjfac*3.55e-4*coldry*1e-20 with a default-real 3.55e-4 (rrtmg_lw_taumol.f90:2479)
       const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, 3.55e-4, 1.e20, 3.0, 2.0, 0.68, (double)3.55e-4f);
-      const double absco2 = lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
-      const double absco = lw_minor2(t + B.ma[1], 9, ig, sm3.js, sm3.fs, s);
+      const V<G> absco2 = lw_minor2(ma0, 9, sm.js, sm.fs, s);
+      const V<G> absco = lw_minor2(ma1, 9, sm3.js, sm3.fs, s);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 + s.colco * absco;
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      const double abso3 = lw_minor1(t + B.mb[0], ig, s);
+      const V<G> abso3 = lw_minor1(mb0, s);
       taug = s.colo3 * abso3;
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 14) {
     if (lower) {
       taug = s.colco2 * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s);
-      fracs = t[B.fraca + ig];
+      fracs = fraca[0];
     } else {
       taug = s.colco2 * lw_m4(absb, u0s, u1s, s);
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   } else if constexpr (BAND == 15) {
     // lower n2o/co2, minor n2 ; nothing above
     if (lower) {
-      const LwSpec sp = lw_spec(s.coln2o, chirat(4, 2, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.coln2o, chirat(4, 2, s.jp + 1), s.colco2, 8.0);
-      const LwSpec sm = lw_spec(s.coln2o, chirat(4, 2, 1), s.colco2, 8.0), pl = lw_spec(s.coln2o, chirat(4, 2, 1), s.colco2, 8.0);
+      const LwSpec sp = lw_spec(s.coln2o, chirat(CR_42, s.jp), s.colco2, 8.0), sp1 = lw_spec(s.coln2o, chirat(CR_42, s.jp + 1), s.colco2, 8.0);
+      const LwSpec sm = lw_spec(s.coln2o, chirat(CR_42, 1), s.colco2, 8.0), pl = lw_spec(s.coln2o, chirat(CR_42, 1), s.colco2, 8.0);
       const double scalen2 = s.colbrd * s.scaleminor;
-      const double taun2 = scalen2 * lw_minor2(t + B.ma[0], 9, ig, sm.js, sm.fs, s);
+      const V<G> taun2 = scalen2 * lw_minor2(ma0, 9, sm.js, sm.fs, s);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s) + taun2;
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
-      taug = 0.0; fracs = 0.0;
+      taug = vsplat<G>(0.0); fracs = vsplat<G>(0.0);
     }
   } else {  // 16
     if (lower) {
-      const LwSpec sp = lw_spec(s.colh2o, chirat(1, 6, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(1, 6, s.jp + 1), s.colch4, 8.0);
-      const LwSpec pl = lw_spec(s.colh2o, chirat(1, 6, 6), s.colch4, 8.0);
+      const LwSpec sp = lw_spec(s.colh2o, chirat(CR_16, s.jp), s.colch4, 8.0), sp1 = lw_spec(s.colh2o, chirat(CR_16, s.jp + 1), s.colch4, 8.0);
+      const LwSpec pl = lw_spec(s.colh2o, chirat(CR_16, 6), s.colch4, 8.0);
       taug = lw_major_lower(absa, i0s * 9 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_lower(absa, i1s * 9 + sp1.js - 1, sp1, s.fac01, s.fac11) +
              lw_tauself(selfref, s) + lw_taufor(forref, s);
-      fracs = lw_frac2(t + B.fraca, ng, ig, pl);
+      fracs = lw_frac2(fraca, pl);
     } else {
       taug = s.colch4 * lw_m4(absb, u0s, u1s, s);
-      fracs = t[B.fracb + ig];
+      fracs = fracb[0];
     }
   }
   return taug;
@@ -701,11 +725,11 @@ RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
 
 enum { LF_ATRANS = 0, LF_BBUGAS, LF_ATOT, LF_BBUTOT, LF_N };
 
-// Per-g-point radiance sink used by the host emulation: band-weighted radiances of every g-point go to
-// part[g][k][level][column], k = 0 up, 1 down, 2 clear up, 3 clear down, (4, 5 = d/dTs of 0, 2 with idrv).
-// The device kernel uses a block-reducing sink instead (rrtmg_lw.hip).
+// Per-item radiance sink (host emulation, tests and the device kernel): the band-weighted radiances, summed over
+// the item's g-points, go to part[item][k][level][column], k = 0 up, 1 down, 2 clear up, 3 clear down,
+// (4, 5 = d/dTs of 0, 2 with idrv).
 struct LwPartSink {
-  double *p;       // part + (iw*nk*(L+1))*N + col
+  double *p;       // part + (slot*nk*(L+1))*N + col
   long N, st;      // st = (L+1)*N
   bool idrv;
   RRTMG_HD void dn(int lev, double rd, double rcd) { p[st + (long)lev * N] = rd; p[3 * st + (long)lev * N] = rcd; }
@@ -714,52 +738,60 @@ struct LwPartSink {
     if (idrv) { p[4 * st + (long)lev * N] = du; p[5 * st + (long)lev * N] = dcu; }
   }
 };
-RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int iw, int col) {
+RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   LwPartSink s;
   const int nk = d.idrv ? 6 : 4;
   s.N = d.ncol; s.st = (long)(d.nlay + 1) * d.ncol; s.idrv = d.idrv != 0;
-  s.p = d.part + ((long)iw * nk * (d.nlay + 1)) * d.ncol + col;
+  s.p = d.part + ((long)slot * nk * (d.nlay + 1)) * d.ncol + col;
   return s;
 }
 
-// One (column, g-point): rtrn / rtrnmc for this g-point (rrtmg_lw_rtrn.f90:324-525).  Radiances leave through
-// `sink` already weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543), so partial sums may span bands.
-template <int BAND, class Sink>
-RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, double *scr, long stride, Sink &sink) {
+// McICA cloud-mask bit of (sub-column iw, layer l) / of the OR over all sub-columns
+RRTMG_HD bool lw_mask_bit(const LwDev &d, int iw, int col, int l) {
+  return (d.mask[((long)iw * d.nw + (l >> 6)) * d.ncol + col] >> (l & 63)) & 1ull;
+}
+RRTMG_HD bool lw_anymask_bit(const LwDev &d, int col, int l) {
+  return (d.anymask[(long)(l >> 6) * d.ncol + col] >> (l & 63)) & 1ull;
+}
+
+// One (column, work item): rtrn / rtrnmc for the item's G g-points (rrtmg_lw_rtrn.f90:324-525).  The layer
+// state, the species mixtures, the Planck functions and the cloud optics are evaluated once for the G g-points.
+// Radiances leave through `sink` weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543) and summed over
+// the item's g-points in g-point order.
+template <int BAND, int G, class Sink>
+RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
   const int ib = BAND - 1;
-  const int iw = T.b[ib].gs + ig;
+  const int iw0 = T.b[ib].gs + ig0;
   const double *t = T.t;
   const double *exp_tbl = t + T.exp_tbl, *tau_tbl = t + T.tau_tbl, *tfn_tbl = t + T.tfn_tbl;
   const double rec_6 = 0.166667;
   const int laytrop = d.laytrop[col];
   const double secd = d.secdiff[(long)ib * N + col];
   const double wtdiff = 0.5, delw = t[T.delwave + ib];
-  (void)iw;
-  auto S = [&](int f, int l) -> double & { return scr[((long)l * LF_N + f) * stride]; };
+#ifdef RRTMG_ABL_NOSCRATCH
+  auto S = [&](int f, int l, int g) -> double & { (void)l; return scr[(((long)0 * LF_N + f) * G + g) * stride]; };
+#else
+  auto S = [&](int f, int l, int g) -> double & { return scr[(((long)l * LF_N + f) * G + g) * stride]; };
+#endif
   auto W = [&](double r) { return (r * wtdiff) * delw; };
 
   // cloud bookkeeping
   const bool clouds = d.icld >= 1 && d.cldfr != nullptr;
-  uint64_t mw[4] = {0, 0, 0, 0}, aw[4] = {0, 0, 0, 0};
   int cb = 0;           // cloud band index used for odcld / efclfrac (non-McICA)
   double secd_cb = secd;
-  if (clouds) {
-    if (d.mcica) {
-#pragma unroll
-      for (int w = 0; w < 4; ++w) if (w < d.nw) { mw[w] = d.mask[((long)iw * d.nw + w) * N + col]; aw[w] = d.anymask[(long)w * N + col]; }
-    } else {
-      const int ncb = d.ncbands[col];
-      const int ipat1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
-      cb = ncb == 1 ? 0 : (ncb == 5 ? ipat1[ib] - 1 : ib);
-      secd_cb = d.secdiff[(long)cb * N + col];   // odcld(lay,ib) = secdiff(ib)*taucloud(lay,ib): cloud-band index
-    }
+  if (clouds && !d.mcica) {
+    const int ncb = d.ncbands[col];
+    const int ipat1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
+    cb = ncb == 1 ? 0 : (ncb == 5 ? ipat1[ib] - 1 : ib);
+    secd_cb = d.secdiff[(long)cb * N + col];   // odcld(lay,ib) = secdiff(ib)*taucloud(lay,ib): cloud-band index
   }
 
   // ---- downward sweep, lev = L .. 1 ---------------------------------------------------------
-  double radld = 0.0, radclrd = 0.0;
-  int iclddn = 0;
-  double plfrac_bot = 0.0;
+  double radld[G], radclrd[G], plfrac_bot[G];
+  int iclddn[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; }
   sink.dn(L, 0.0, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
   for (int lev = L; lev >= 1; --lev) {
@@ -767,177 +799,248 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig, d
     const long i = (long)l * N + col;
     LwLayerIn s;
     lw_load_layer(d, col, l, s);
-    double plfrac;
-    const double taug = lw_taug<BAND>(T, s, lev <= laytrop, ig, plfrac);
+    V<G> plfrac;
+#ifdef RRTMG_ABL_NOTAUG
+    plfrac = vsplat<G>(0.1); const V<G> taug = vsplat<G>(s.colh2o * 1.0e-3 + s.fac00);
+#else
+    const V<G> taug = lw_taug<BAND, G>(T, s, lev <= laytrop, ig0, plfrac);
+#endif
     const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
-    const double taut = taug + taua;
     const double tz_dn = d.tlev[i];
+#ifdef RRTMG_ABL_NOPLANCK
+    const double blay = d.tlay[i], dplankup = tz_up - blay, dplankdn = tz_dn - blay;
+#else
     const double blay = lw_planck(T, ib, d.tlay[i]);
     const double dplankup = lw_planck(T, ib, tz_up) - blay;
     const double dplankdn = lw_planck(T, ib, tz_dn) - blay;
+#endif
     tz_up = tz_dn;
-    double odepth = secd * taut;
-    if (odepth < 0.0) odepth = 0.0;
-    // is this a cloudy layer for the recurrence?
-    bool icldlyr = false;
-    double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
+    // band-level cloud state of this layer (shared by the g-points)
+    bool icldlyr = false, cld_band = false;
+    double cfrac_band = 0.0, odcld_band = 0.0, efcl_band = 0.0;
     if (clouds) {
       if (d.mcica) {
-        icldlyr = mask_bit(aw, l);
-        if (mask_bit(mw, l)) {
-          cfrac = 1.0;
-          odcld = secd * d.ctau[((long)ib * L + l) * N + col];
-          const double transcld = exp(-odcld);
-          efclfrac = (1.0 - transcld) * cfrac;
+        icldlyr = lw_anymask_bit(d, col, l);
+        if (icldlyr) {
+          odcld_band = secd * d.ctau[((long)ib * L + l) * N + col];
+          efcl_band = (1.0 - exp(-odcld_band)) * 1.0;
         }
       } else {
-        cfrac = d.cldfr[i];
-        if (cfrac >= 1.e-6) {
-          icldlyr = true;
-          odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
-          const double transcld = exp(-odcld);
-          efclfrac = (1. - transcld) * cfrac;
+        cfrac_band = d.cldfr[i];
+        if (cfrac_band >= 1.e-6) {
+          icldlyr = true; cld_band = true;
+          odcld_band = secd_cb * d.ctau[((long)cb * L + l) * N + col];
+          efcl_band = (1. - exp(-odcld_band)) * cfrac_band;
         }
       }
     }
-    double atrans, bbd, bbugas;
-    if (icldlyr) {
-      iclddn = 1;
-      double odtot = odepth + odcld;
-      double gassrc, atot, bbdtot, bbutot;
-      if (odtot < 0.06) {
-        atrans = odepth - 0.5 * odepth * odepth;
-        const double odepth_rec = rec_6 * odepth;
-        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans;
-        atot = odtot - 0.5 * odtot * odtot;
-        const double odtot_rec = rec_6 * odtot;
-        bbdtot = plfrac * (blay + dplankdn * odtot_rec);
-        bbd = plfrac * (blay + dplankdn * odepth_rec);
-        bbugas = plfrac * (blay + dplankup * odepth_rec);
-        bbutot = plfrac * (blay + dplankup * odtot_rec);
-      } else if (odepth <= 0.06) {
-        atrans = odepth - 0.5 * odepth * odepth;
-        const double odepth_rec = rec_6 * odepth;
-        gassrc = plfrac * (blay + dplankdn * odepth_rec) * atrans;
-        odtot = odepth + odcld;
-        const double tblind = odtot / (kBpade + odtot);
-        const int ittot = (int)(kTblInt * tblind + 0.5);
-        const double tfactot = tfn_tbl[ittot];
-        bbdtot = plfrac * (blay + tfactot * dplankdn);
-        bbd = plfrac * (blay + dplankdn * odepth_rec);
-        atot = 1.0 - exp_tbl[ittot];
-        bbugas = plfrac * (blay + dplankup * odepth_rec);
-        bbutot = plfrac * (blay + tfactot * dplankup);
-      } else {
-        double tblind = odepth / (kBpade + odepth);
-        const int itgas = (int)(kTblInt * tblind + 0.5);
-        odepth = tau_tbl[itgas];
-        atrans = 1.0 - exp_tbl[itgas];
-        const double tfacgas = tfn_tbl[itgas];
-        gassrc = atrans * plfrac * (blay + tfacgas * dplankdn);
-        odtot = odepth + odcld;
-        tblind = odtot / (kBpade + odtot);
-        const int ittot = (int)(kTblInt * tblind + 0.5);
-        const double tfactot = tfn_tbl[ittot];
-        bbdtot = plfrac * (blay + tfactot * dplankdn);
-        bbd = plfrac * (blay + tfacgas * dplankdn);
-        atot = 1.0 - exp_tbl[ittot];
-        bbugas = plfrac * (blay + tfacgas * dplankup);
-        bbutot = plfrac * (blay + tfactot * dplankup);
+    double srd = 0.0, srcd = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double plf = plfrac[g];
+      const double taut = taug[g] + taua;
+      double odepth = secd * taut;
+      if (odepth < 0.0) odepth = 0.0;
+      double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
+      if (icldlyr) {
+        if (d.mcica) {
+          if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; odcld = odcld_band; efclfrac = efcl_band; }
+        } else if (cld_band) {
+          cfrac = cfrac_band; odcld = odcld_band; efclfrac = efcl_band;
+        }
       }
-      radld = radld - radld * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
-      S(LF_ATOT, l) = atot;
-      S(LF_BBUTOT, l) = bbutot;
-    } else {
-      if (odepth <= 0.06) {
-        atrans = odepth - 0.5 * odepth * odepth;
-        odepth = rec_6 * odepth;
-        bbd = plfrac * (blay + dplankdn * odepth);
-        bbugas = plfrac * (blay + dplankup * odepth);
+      double atrans, bbd, bbugas;
+      if (icldlyr) {
+        iclddn[g] = 1;
+        double odtot = odepth + odcld;
+        double gassrc, atot, bbdtot, bbutot;
+        if (odtot < 0.06) {
+          atrans = odepth - 0.5 * odepth * odepth;
+          const double odepth_rec = rec_6 * odepth;
+          gassrc = plf * (blay + dplankdn * odepth_rec) * atrans;
+          atot = odtot - 0.5 * odtot * odtot;
+          const double odtot_rec = rec_6 * odtot;
+          bbdtot = plf * (blay + dplankdn * odtot_rec);
+          bbd = plf * (blay + dplankdn * odepth_rec);
+          bbugas = plf * (blay + dplankup * odepth_rec);
+          bbutot = plf * (blay + dplankup * odtot_rec);
+        } else if (odepth <= 0.06) {
+          atrans = odepth - 0.5 * odepth * odepth;
+          const double odepth_rec = rec_6 * odepth;
+          gassrc = plf * (blay + dplankdn * odepth_rec) * atrans;
+          odtot = odepth + odcld;
+          const double tblind = odtot / (kBpade + odtot);
+          const int ittot = (int)(kTblInt * tblind + 0.5);
+          const double tfactot = tfn_tbl[ittot];
+          bbdtot = plf * (blay + tfactot * dplankdn);
+          bbd = plf * (blay + dplankdn * odepth_rec);
+          atot = 1.0 - exp_tbl[ittot];
+          bbugas = plf * (blay + dplankup * odepth_rec);
+          bbutot = plf * (blay + tfactot * dplankup);
+        } else {
+          double tblind = odepth / (kBpade + odepth);
+          const int itgas = (int)(kTblInt * tblind + 0.5);
+          odepth = tau_tbl[itgas];
+          atrans = 1.0 - exp_tbl[itgas];
+          const double tfacgas = tfn_tbl[itgas];
+          gassrc = atrans * plf * (blay + tfacgas * dplankdn);
+          odtot = odepth + odcld;
+          tblind = odtot / (kBpade + odtot);
+          const int ittot = (int)(kTblInt * tblind + 0.5);
+          const double tfactot = tfn_tbl[ittot];
+          bbdtot = plf * (blay + tfactot * dplankdn);
+          bbd = plf * (blay + tfacgas * dplankdn);
+          atot = 1.0 - exp_tbl[ittot];
+          bbugas = plf * (blay + tfacgas * dplankup);
+          bbutot = plf * (blay + tfactot * dplankup);
+        }
+        radld[g] = radld[g] - radld[g] * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
+        S(LF_ATOT, l, g) = atot;
+        S(LF_BBUTOT, l, g) = bbutot;
       } else {
-        const double tblind = odepth / (kBpade + odepth);
-        const int itr = (int)(kTblInt * tblind + 0.5);
-        const double transc = exp_tbl[itr];
-        atrans = 1.0 - transc;
-        const double tausfac = tfn_tbl[itr];
-        bbd = plfrac * (blay + tausfac * dplankdn);
-        bbugas = plfrac * (blay + tausfac * dplankup);
+        if (odepth <= 0.06) {
+          atrans = odepth - 0.5 * odepth * odepth;
+          odepth = rec_6 * odepth;
+          bbd = plf * (blay + dplankdn * odepth);
+          bbugas = plf * (blay + dplankup * odepth);
+        } else {
+          const double tblind = odepth / (kBpade + odepth);
+          const int itr = (int)(kTblInt * tblind + 0.5);
+          const double transc = exp_tbl[itr];
+          atrans = 1.0 - transc;
+          const double tausfac = tfn_tbl[itr];
+          bbd = plf * (blay + tausfac * dplankdn);
+          bbugas = plf * (blay + tausfac * dplankup);
+        }
+        radld[g] = radld[g] + (bbd - radld[g]) * atrans;
       }
-      radld = radld + (bbd - radld) * atrans;
+      S(LF_ATRANS, l, g) = atrans;
+      S(LF_BBUGAS, l, g) = bbugas;
+      if (iclddn[g] == 1) {
+        radclrd[g] = radclrd[g] + (bbd - radclrd[g]) * atrans;
+      } else {
+        radclrd[g] = radld[g];
+      }
+      srd = srd + W(radld[g]); srcd = srcd + W(radclrd[g]);
+      plfrac_bot[g] = plf;
     }
-    S(LF_ATRANS, l) = atrans;
-    S(LF_BBUGAS, l) = bbugas;
-    if (iclddn == 1) {
-      radclrd = radclrd + (bbd - radclrd) * atrans;
-    } else {
-      radclrd = radld;
-    }
-    sink.dn(lev - 1, W(radld), W(radclrd));
-    plfrac_bot = plfrac;
+    sink.dn(lev - 1, srd, srcd);
   }
 
   // ---- surface ------------------------------------------------------------------------------
   const double semiss = d.emis[(long)ib * N + col];
   const double tbound = d.tsfc[col];
   const double plankbnd = semiss * lw_planck(T, ib, tbound);
-  const double rad0 = plfrac_bot * plankbnd;
   const double reflect = 1.0 - semiss;
-  double radlu = rad0 + reflect * radld;
-  double radclru = rad0 + reflect * radclrd;
-  double d_radlu_dt = 0.0, d_radclru_dt = 0.0;
-  if (d.idrv) {
-    const double d_rad0_dt = plfrac_bot * (semiss * lw_planck_deriv(T, ib, tbound));
-    d_radlu_dt = d_rad0_dt; d_radclru_dt = d_rad0_dt;
+  double radlu[G], radclru[G], d_radlu_dt[G], d_radclru_dt[G];
+  {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double rad0 = plfrac_bot[g] * plankbnd;
+      radlu[g] = rad0 + reflect * radld[g];
+      radclru[g] = rad0 + reflect * radclrd[g];
+      d_radlu_dt[g] = 0.0; d_radclru_dt[g] = 0.0;
+      if (d.idrv) {
+        const double d_rad0_dt = plfrac_bot[g] * (semiss * lw_planck_deriv(T, ib, tbound));
+        d_radlu_dt[g] = d_rad0_dt; d_radclru_dt[g] = d_rad0_dt;
+      }
+      s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
+    }
+    sink.up(0, s0, s1, s2, s3);
   }
-  sink.up(0, W(radlu), W(radclru), W(d_radlu_dt), W(d_radclru_dt));
 
   // ---- upward sweep ---------------------------------------------------------------------------
   for (int lev = 1; lev <= L; ++lev) {
     const int l = lev - 1;
-    const double atrans = S(LF_ATRANS, l), bbugas = S(LF_BBUGAS, l);
-    bool icldlyr = false;
-    double cfrac = 0.0, efclfrac = 0.0;
+    bool icldlyr = false, cld_band = false;
+    double cfrac_band = 0.0, efcl_band = 0.0;
     if (clouds) {
       if (d.mcica) {
-        icldlyr = mask_bit(aw, l);
-        if (mask_bit(mw, l)) {
-          cfrac = 1.0;
+        icldlyr = lw_anymask_bit(d, col, l);
+        if (icldlyr) {
           const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
-          efclfrac = (1.0 - exp(-odcld)) * cfrac;
+          efcl_band = (1.0 - exp(-odcld)) * 1.0;
         }
       } else {
-        cfrac = d.cldfr[(long)l * N + col];
-        if (cfrac >= 1.e-6) {
-          icldlyr = true;
+        cfrac_band = d.cldfr[(long)l * N + col];
+        if (cfrac_band >= 1.e-6) {
+          icldlyr = true; cld_band = true;
           const double odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
-          efclfrac = (1. - exp(-odcld)) * cfrac;
+          efcl_band = (1. - exp(-odcld)) * cfrac_band;
         }
       }
     }
-    if (icldlyr) {
-      const double atot = S(LF_ATOT, l), bbutot = S(LF_BBUTOT, l);
-      const double gassrc = bbugas * atrans;
-      radlu = radlu - radlu * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
-      if (d.idrv) d_radlu_dt = d_radlu_dt * cfrac * (1.0 - atot) + d_radlu_dt * (1.0 - cfrac) * (1.0 - atrans);
-    } else {
-      radlu = radlu + (bbugas - radlu) * atrans;
-      if (d.idrv) d_radlu_dt = d_radlu_dt * (1.0 - atrans);
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double atrans = S(LF_ATRANS, l, g), bbugas = S(LF_BBUGAS, l, g);
+      double cfrac = 0.0, efclfrac = 0.0;
+      if (icldlyr) {
+        if (d.mcica) {
+          if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; efclfrac = efcl_band; }
+        } else if (cld_band) {
+          cfrac = cfrac_band; efclfrac = efcl_band;
+        }
+      }
+      if (icldlyr) {
+        const double atot = S(LF_ATOT, l, g), bbutot = S(LF_BBUTOT, l, g);
+        const double gassrc = bbugas * atrans;
+        radlu[g] = radlu[g] - radlu[g] * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
+        if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * cfrac * (1.0 - atot) + d_radlu_dt[g] * (1.0 - cfrac) * (1.0 - atrans);
+      } else {
+        radlu[g] = radlu[g] + (bbugas - radlu[g]) * atrans;
+        if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * (1.0 - atrans);
+      }
+      if (iclddn[g] == 1) {
+        radclru[g] = radclru[g] + (bbugas - radclru[g]) * atrans;
+        if (d.idrv) d_radclru_dt[g] = d_radclru_dt[g] * (1.0 - atrans);
+      } else {
+        radclru[g] = radlu[g];
+        if (d.idrv) d_radclru_dt[g] = d_radlu_dt[g];
+      }
+      s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
     }
-    if (iclddn == 1) {
-      radclru = radclru + (bbugas - radclru) * atrans;
-      if (d.idrv) d_radclru_dt = d_radclru_dt * (1.0 - atrans);
-    } else {
-      radclru = radlu;
-      if (d.idrv) d_radclru_dt = d_radlu_dt;
-    }
-    sink.up(lev, W(radlu), W(radclru), W(d_radlu_dt), W(d_radclru_dt));
+    sink.up(lev, s0, s1, s2, s3);
+  }
+}
+
+// Dispatch of one work item (packed, see LwTab) for one column: band switch + G in {4, 2}.
+template <int BAND, class Sink>
+RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
+  constexpr int ng = kLwNg[BAND - 1];
+  if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
+    if (g == 4) { lw_solve_thread<BAND, 4>(d, T, col, ig0, scr, stride, sink); return; }
+  }
+  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2>(d, T, col, ig0, scr, stride, sink);
+}
+template <class Sink>
+RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, double *scr, long stride, Sink &sink) {
+  const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
+  switch ((item & 0xff) + 1) {
+    case 1: lw_solve_band<1>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 2: lw_solve_band<2>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 3: lw_solve_band<3>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 4: lw_solve_band<4>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 5: lw_solve_band<5>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 6: lw_solve_band<6>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 7: lw_solve_band<7>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 8: lw_solve_band<8>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 9: lw_solve_band<9>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 10: lw_solve_band<10>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 11: lw_solve_band<11>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 12: lw_solve_band<12>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 13: lw_solve_band<13>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 14: lw_solve_band<14>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 15: lw_solve_band<15>(d, T, g, col, ig0, scr, stride, sink); break;
+    default: lw_solve_band<16>(d, T, g, col, ig0, scr, stride, sink); break;
   }
 }
 
 // band / g-point integration and heating rates (rrtmg_lw_rtrn.f90:528-585)
 // one thread per (column, interface level)
-// nparts = 140 (per-g-point partials, host emulation) or 35 (block-reduced partials of the device kernel);
-// the partials already carry wtdiff*delwave(band)
+// nparts = number of work items (T.nitem); each partial is the sum over its item's g-points and already carries
+// wtdiff*delwave(band)
 RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts) {
   (void)T;
   const int L = d.nlay, N = d.ncol;

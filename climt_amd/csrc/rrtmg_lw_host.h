@@ -2,6 +2,7 @@
 #pragma once
 #include <cmath>
 #include <string>
+#include <vector>
 
 #include "rrtmg_lw_device.h"
 #include "rrtmg_tables.h"
@@ -31,13 +32,24 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
     const std::string p = buf;
     B.ng = (*ngc)[b];
     B.gs = b == 0 ? 0 : (*ngs)[b - 1];
-    B.absa = off(p + "absa", true); B.absb = off(p + "absb", false);
-    B.self = off(p + "selfref", true); B.forr = off(p + "forref", true);
+    if (B.ng != kLwNg[b]) { err = "reduced g-point count of band " + std::to_string(b + 1) + " differs from the compiled-in one"; return false; }
+    // g-point-fastest copies ([row][ng]) of the per-g-point tables ([ng][row]) for the vector loads of the kernel
+    auto gfast = [&](const std::string &n, bool required) -> long {
+      auto it = ts.reg.find(p + n);
+      if (it == ts.reg.end()) { if (required) err = "reduced table '" + p + n + "' missing"; return 0; }
+      const long o = it->second.off, rows = it->second.n / B.ng;
+      std::vector<double> tr((size_t)it->second.n);
+      for (int ig = 0; ig < B.ng; ++ig)
+        for (long r = 0; r < rows; ++r) tr[(size_t)r * B.ng + ig] = ts.flat[(size_t)o + (size_t)ig * rows + r];
+      return ts.add(p + n + "_g", tr.data(), (long)tr.size(), {(uint32_t)rows, (uint32_t)B.ng});
+    };
+    B.absa = gfast("absa", true); B.absb = gfast("absb", false);
+    B.self = gfast("selfref", true); B.forr = gfast("forref", true);
     B.fraca = off(p + "fracrefa", true); B.fracb = off(p + "fracrefb", false);
     { auto it = ts.reg.find(p + "fracrefa"); B.nfraca = it != ts.reg.end() && it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
     { auto it = ts.reg.find(p + "fracrefb"); B.nfracb = it != ts.reg.end() && it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
-    for (int k = 0; k < 3; ++k) B.ma[k] = MA[b][k] ? off(p + MA[b][k], true) : 0;
-    for (int k = 0; k < 2; ++k) B.mb[k] = MB[b][k] ? off(p + MB[b][k], true) : 0;
+    for (int k = 0; k < 3; ++k) B.ma[k] = MA[b][k] ? gfast(MA[b][k], true) : 0;
+    for (int k = 0; k < 2; ++k) B.mb[k] = MB[b][k] ? gfast(MB[b][k], true) : 0;
     for (int k = 0; k < 2; ++k) B.x[k] = X[b][k] ? off(p + X[b][k], true) : 0;
     if (!err.empty()) return false;
   }
@@ -50,6 +62,33 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
   T.absice2 = off("lw/cld/absice2", true); T.absice3 = off("lw/cld/absice3", true); T.absliq0 = off("lw/cld/absliq0", true);
   T.absliq1 = off("lw/cld/absliq1", true);
   T.heatfac = ts.heatfac;
+  // chi_mls(x, j)/chi_mls(y, j) of the binary-species bands (rrtmg_lw_setcoef.f90 rat_* quotients), rows CR_*
+  {
+    const int pair[CR_N][2] = {{1, 2}, {3, 2}, {1, 3}, {1, 6}, {1, 4}, {4, 2}};
+    std::vector<double> cr((size_t)CR_N * 59);
+    for (int q = 0; q < CR_N; ++q)
+      for (int j = 1; j <= 59; ++j)
+        cr[(size_t)q * 59 + (j - 1)] = ts.flat[(size_t)T.chi_mls + (pair[q][0] - 1) + 7 * (j - 1)] / ts.flat[(size_t)T.chi_mls + (pair[q][1] - 1) + 7 * (j - 1)];
+    T.chirat = ts.add("lw/ref/chirat", cr.data(), (long)cr.size(), {59u, (uint32_t)CR_N});
+  }
+  // work items: chunks of 4 (then 2) consecutive g-points of a band; launch order heaviest first
+  T.nitem = 0;
+  double cost[kLwMaxItem];
+  const int nspa[kLwNBand] = {1, 1, 9, 9, 9, 1, 9, 1, 9, 1, 1, 9, 9, 1, 9, 9};
+  for (int b = 0; b < kLwNBand; ++b) {
+    int ig = 0;
+    while (ig < T.b[b].ng) {
+      const int g = (T.b[b].ng - ig >= 4 && RRTMG_LW_GMAX >= 4) ? 4 : 2;
+      if (T.nitem >= kLwMaxItem) { err = "too many work items"; return false; }
+      cost[T.nitem] = (nspa[b] == 9 ? 2.0 : 1.0) + g * 0.7;
+      T.item[T.nitem] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);
+      T.sched[T.nitem] = T.nitem;
+      ++T.nitem;
+      ig += g;
+    }
+  }
+  for (int i = 1; i < T.nitem; ++i)   // stable insertion sort, descending cost
+    for (int j = i; j > 0 && cost[T.sched[j]] > cost[T.sched[j - 1]]; --j) { const int t = T.sched[j]; T.sched[j] = T.sched[j - 1]; T.sched[j - 1] = t; }
   return err.empty();
 }
 

@@ -15,14 +15,12 @@ namespace rrtmg {
 void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
 }
 
-template <int BAND>
 static void emu_lw_solve(const LwDev &d, const LwTab &T) {
-  const int ng = T.b[BAND - 1].ng;
-  std::vector<double> scr((size_t)LF_N * d.nlay);
-  for (int ig = 0; ig < ng; ++ig)
+  std::vector<double> scr((size_t)LF_N * d.nlay * 4);
+  for (int slot = 0; slot < T.nitem; ++slot)
     for (int col = 0; col < d.ncol; ++col) {
-      LwPartSink sink = lw_part_sink(d, T.b[BAND - 1].gs + ig, col);
-      lw_solve_thread<BAND>(d, T, col, ig, scr.data(), 1, sink);
+      LwPartSink sink = lw_part_sink(d, slot, col);
+      lw_solve_item(d, T, T.item[slot], col, scr.data(), 1, sink);
     }
 }
 
@@ -89,10 +87,8 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
       for (int c = 0; c < N; ++c) lw_anymask_column(d, c);
     }
   }
-  emu_lw_solve<1>(d, T); emu_lw_solve<2>(d, T); emu_lw_solve<3>(d, T); emu_lw_solve<4>(d, T); emu_lw_solve<5>(d, T); emu_lw_solve<6>(d, T);
-  emu_lw_solve<7>(d, T); emu_lw_solve<8>(d, T); emu_lw_solve<9>(d, T); emu_lw_solve<10>(d, T); emu_lw_solve<11>(d, T); emu_lw_solve<12>(d, T);
-  emu_lw_solve<13>(d, T); emu_lw_solve<14>(d, T); emu_lw_solve<15>(d, T); emu_lw_solve<16>(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev, kLwNGpt);
+  emu_lw_solve(d, T);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev, T.nitem);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
@@ -102,14 +98,16 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
 template <int BAND>
 static void emu_taug_band(const LwDev &d, const LwTab &T, double *taug, double *fracs) {
   const int L = d.nlay;
-  for (int ig = 0; ig < T.b[BAND - 1].ng; ++ig)
+  for (int ig = 0; ig < T.b[BAND - 1].ng; ig += 2)
     for (int l = 0; l < L; ++l) {
       LwLayerIn s;
       lw_load_layer(d, 0, l, s);
-      double fr;
-      const double tg = lw_taug<BAND>(T, s, (l + 1) <= d.laytrop[0], ig, fr);
-      taug[(size_t)(T.b[BAND - 1].gs + ig) * L + l] = tg;    // Fortran (nlay, ngpt) order
-      fracs[(size_t)(T.b[BAND - 1].gs + ig) * L + l] = fr;
+      V<2> fr;
+      const V<2> tg = lw_taug<BAND, 2>(T, s, (l + 1) <= d.laytrop[0], ig, fr);
+      for (int j = 0; j < 2; ++j) {
+        taug[(size_t)(T.b[BAND - 1].gs + ig + j) * L + l] = tg[j];    // Fortran (nlay, ngpt) order
+        fracs[(size_t)(T.b[BAND - 1].gs + ig + j) * L + l] = fr[j];
+      }
     }
 }
 
