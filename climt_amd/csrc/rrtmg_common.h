@@ -81,6 +81,17 @@ template <int G> RRTMG_HD V<G> vload(const double *p) {
   return r;
 }
 
+// G consecutive doubles to p (16-byte aligned), one 16-byte store per pair
+template <int G> RRTMG_HD void vstore(double *p, const V<G> &x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (G % 2 == 0) {
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) *reinterpret_cast<double2 *>(p + i) = make_double2(x.v[i], x.v[i + 1]);
+    return;
+  }
+#endif
+  _Pragma("unroll") for (int i = 0; i < G; ++i) p[i] = x.v[i];
+}
+
 // g-point-fastest table view: element (row, ig0 + j) at p[row * NG + j], p already offset by the first g-point
 template <int G, int NG> struct KTab {
   const double *p;

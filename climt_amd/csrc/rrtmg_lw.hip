@@ -40,7 +40,7 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 // summed in registers: part[item][k][level][column].  Launch order: items heaviest first (LwTab::sched), tiles
 // fastest (a tile count that is a multiple of 8 keeps a tile on one XCD).  Speed only, never correctness.
 #ifndef RRTMG_LW_WAVES
-#define RRTMG_LW_WAVES 3
+#define RRTMG_LW_WAVES 2
 #endif
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile) {
   const int q = blockIdx.x;
@@ -48,7 +48,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_L
   const int slot = T.sched[k], item = T.item[slot];
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x;
+  double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
   LwPartSink sink = lw_part_sink(d, slot, col);
   lw_solve_item(d, T, item, col, scr, 64, sink);
 }

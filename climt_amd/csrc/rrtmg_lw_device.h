@@ -769,10 +769,12 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   const int laytrop = d.laytrop[col];
   const double secd = d.secdiff[(long)ib * N + col];
   const double wtdiff = 0.5, delw = t[T.delwave + ib];
+  // scratch slab of this (tile, item): [layer][field][lane][G] -- the G values of a lane are one 16/32-byte access;
+  // scr points at this lane's first element, stride = lanes per row (64 on the device, 1 in the host emulation)
 #ifdef RRTMG_ABL_NOSCRATCH
-  auto S = [&](int f, int l, int g) -> double & { (void)l; return scr[(((long)0 * LF_N + f) * G + g) * stride]; };
+  auto SP = [&](int f, int l) -> double * { (void)l; return scr + ((long)0 * LF_N + f) * stride * G; };
 #else
-  auto S = [&](int f, int l, int g) -> double & { return scr[(((long)l * LF_N + f) * G + g) * stride]; };
+  auto SP = [&](int f, int l) -> double * { return scr + ((long)l * LF_N + f) * stride * G; };
 #endif
   auto W = [&](double r) { return (r * wtdiff) * delw; };
 
@@ -835,6 +837,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       }
     }
     double srd = 0.0, srcd = 0.0;
+    V<G> v_atrans, v_bbugas, v_atot, v_bbutot;
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const double plf = plfrac[g];
@@ -895,8 +898,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbutot = plf * (blay + tfactot * dplankup);
         }
         radld[g] = radld[g] - radld[g] * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
-        S(LF_ATOT, l, g) = atot;
-        S(LF_BBUTOT, l, g) = bbutot;
+        v_atot[g] = atot;
+        v_bbutot[g] = bbutot;
       } else {
         if (odepth <= 0.06) {
           atrans = odepth - 0.5 * odepth * odepth;
@@ -914,8 +917,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         }
         radld[g] = radld[g] + (bbd - radld[g]) * atrans;
       }
-      S(LF_ATRANS, l, g) = atrans;
-      S(LF_BBUGAS, l, g) = bbugas;
+      v_atrans[g] = atrans;
+      v_bbugas[g] = bbugas;
       if (iclddn[g] == 1) {
         radclrd[g] = radclrd[g] + (bbd - radclrd[g]) * atrans;
       } else {
@@ -924,6 +927,9 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       srd = srd + W(radld[g]); srcd = srcd + W(radclrd[g]);
       plfrac_bot[g] = plf;
     }
+    vstore<G>(SP(LF_ATRANS, l), v_atrans);
+    vstore<G>(SP(LF_BBUGAS, l), v_bbugas);
+    if (icldlyr) { vstore<G>(SP(LF_ATOT, l), v_atot); vstore<G>(SP(LF_BBUTOT, l), v_bbutot); }
     sink.dn(lev - 1, srd, srcd);
   }
 
@@ -950,58 +956,70 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     sink.up(0, s0, s1, s2, s3);
   }
 
-  // ---- upward sweep ---------------------------------------------------------------------------
-  for (int lev = 1; lev <= L; ++lev) {
-    const int l = lev - 1;
-    bool icldlyr = false, cld_band = false;
-    double cfrac_band = 0.0, efcl_band = 0.0;
-    if (clouds) {
-      if (d.mcica) {
-        icldlyr = lw_anymask_bit(d, col, l);
-        if (icldlyr) {
-          const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
-          efcl_band = (1.0 - exp(-odcld)) * 1.0;
-        }
-      } else {
-        cfrac_band = d.cldfr[(long)l * N + col];
-        if (cfrac_band >= 1.e-6) {
-          icldlyr = true; cld_band = true;
-          const double odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
-          efcl_band = (1. - exp(-odcld)) * cfrac_band;
-        }
-      }
-    }
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+  // ---- upward sweep: kU layers at a time, their scratch rows are loaded before the first is used ----------
+  constexpr int kU = 4;
+  for (int lev0 = 1; lev0 <= L; lev0 += kU) {
+    V<G> r_atrans[kU], r_bbugas[kU];
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const double atrans = S(LF_ATRANS, l, g), bbugas = S(LF_BBUGAS, l, g);
-      double cfrac = 0.0, efclfrac = 0.0;
-      if (icldlyr) {
+    for (int u = 0; u < kU; ++u)
+      if (lev0 + u <= L) { r_atrans[u] = vload<G>(SP(LF_ATRANS, lev0 + u - 1)); r_bbugas[u] = vload<G>(SP(LF_BBUGAS, lev0 + u - 1)); }
+#pragma unroll
+    for (int u = 0; u < kU; ++u) {
+      const int lev = lev0 + u;
+      if (lev > L) break;
+      const int l = lev - 1;
+      bool icldlyr = false, cld_band = false;
+      double cfrac_band = 0.0, efcl_band = 0.0;
+      if (clouds) {
         if (d.mcica) {
-          if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; efclfrac = efcl_band; }
-        } else if (cld_band) {
-          cfrac = cfrac_band; efclfrac = efcl_band;
+          icldlyr = lw_anymask_bit(d, col, l);
+          if (icldlyr) {
+            const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
+            efcl_band = (1.0 - exp(-odcld)) * 1.0;
+          }
+        } else {
+          cfrac_band = d.cldfr[(long)l * N + col];
+          if (cfrac_band >= 1.e-6) {
+            icldlyr = true; cld_band = true;
+            const double odcld = secd_cb * d.ctau[((long)cb * L + l) * N + col];
+            efcl_band = (1. - exp(-odcld)) * cfrac_band;
+          }
         }
       }
-      if (icldlyr) {
-        const double atot = S(LF_ATOT, l, g), bbutot = S(LF_BBUTOT, l, g);
-        const double gassrc = bbugas * atrans;
-        radlu[g] = radlu[g] - radlu[g] * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
-        if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * cfrac * (1.0 - atot) + d_radlu_dt[g] * (1.0 - cfrac) * (1.0 - atrans);
-      } else {
-        radlu[g] = radlu[g] + (bbugas - radlu[g]) * atrans;
-        if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * (1.0 - atrans);
+      V<G> r_atot, r_bbutot;
+      if (icldlyr) { r_atot = vload<G>(SP(LF_ATOT, l)); r_bbutot = vload<G>(SP(LF_BBUTOT, l)); }
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double atrans = r_atrans[u][g], bbugas = r_bbugas[u][g];
+        double cfrac = 0.0, efclfrac = 0.0;
+        if (icldlyr) {
+          if (d.mcica) {
+            if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; efclfrac = efcl_band; }
+          } else if (cld_band) {
+            cfrac = cfrac_band; efclfrac = efcl_band;
+          }
+        }
+        if (icldlyr) {
+          const double atot = r_atot[g], bbutot = r_bbutot[g];
+          const double gassrc = bbugas * atrans;
+          radlu[g] = radlu[g] - radlu[g] * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
+          if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * cfrac * (1.0 - atot) + d_radlu_dt[g] * (1.0 - cfrac) * (1.0 - atrans);
+        } else {
+          radlu[g] = radlu[g] + (bbugas - radlu[g]) * atrans;
+          if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * (1.0 - atrans);
+        }
+        if (iclddn[g] == 1) {
+          radclru[g] = radclru[g] + (bbugas - radclru[g]) * atrans;
+          if (d.idrv) d_radclru_dt[g] = d_radclru_dt[g] * (1.0 - atrans);
+        } else {
+          radclru[g] = radlu[g];
+          if (d.idrv) d_radclru_dt[g] = d_radlu_dt[g];
+        }
+        s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
       }
-      if (iclddn[g] == 1) {
-        radclru[g] = radclru[g] + (bbugas - radclru[g]) * atrans;
-        if (d.idrv) d_radclru_dt[g] = d_radclru_dt[g] * (1.0 - atrans);
-      } else {
-        radclru[g] = radlu[g];
-        if (d.idrv) d_radclru_dt[g] = d_radlu_dt[g];
-      }
-      s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
+      sink.up(lev, s0, s1, s2, s3);
     }
-    sink.up(lev, s0, s1, s2, s3);
   }
 }
 

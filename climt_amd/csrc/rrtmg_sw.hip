@@ -64,12 +64,23 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 #ifndef RRTMG_SW_WAVES
 #define RRTMG_SW_WAVES 4
 #endif
-constexpr int kSwWgWaves = 8;
+#ifdef RRTMG_SW_NOLDS
+constexpr int kSwWgWaves = 1;
+#else
+#ifndef RRTMG_SW_WGWAVES
+#define RRTMG_SW_WGWAVES 8
+#endif
+constexpr int kSwWgWaves = RRTMG_SW_WGWAVES;
+#endif
 constexpr int kExpTblN = 10001;
 __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile) {
+#ifdef RRTMG_SW_NOLDS
+  const double *sh_exp = T.t + T.exp_tbl;
+#else
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
   __syncthreads();
+#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x;
