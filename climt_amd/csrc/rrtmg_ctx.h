@@ -27,6 +27,10 @@ struct rrtmg_ctx {
   hipStream_t stream_lw = nullptr;   // longwave in deferred mode, so SW and LW launches overlap on the GPU
   bool deferred = false;             // rrtmg_hip_set_deferred: device-resident calls return after enqueueing
   bool pending[2] = {false, false};  // [sw|lw] enqueued, status not yet collected
+  // KISS jump-ahead operators [sw|lw]: host copy, the key they were built for, the device buffer they were uploaded to
+  std::vector<uint32_t> kiss_host[2];
+  int kiss_key[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
+  const void *kiss_dev[2] = {nullptr, nullptr};
   std::string err;
   int status = 0;
   rrtmg::Constants k{};

@@ -1,14 +1,40 @@
 // rrtmg_mcica_kernels.h -- McICA sub-column mask kernels shared by the SW and LW translation units
 // (static: each TU carries its own device copy; no relocatable device code needed).
 #pragma once
-#include "rrtmg_sw_device.h"   // kiss_mask_column
+#include "rrtmg_ctx.h"
+#include "rrtmg_kiss_host.h"
+#include "rrtmg_sw_device.h"   // kiss_mask_jump
 
 namespace rrtmg {
 
-static __global__ void __launch_bounds__(64) kiss_mask_kernel(int ncol, int nlay, int nsub, int icld, int seed, const double *play,
-                                                              const double *cldfr, uint64_t *mask, int nw, int *err) {
+// kissvec sub-columns, one thread per (column, sub-column): grid (tiles, nsub).  Every thread jumps the column's
+// generator to its sub-column's first draw (kiss_jump) -- nsub times the parallelism of the column-sequential
+// reference order, same bits.
+static __global__ void __launch_bounds__(64) kiss_mask_kernel(int ncol, int nlay, int icld, const double *play, const double *cldfr,
+                                                              uint64_t *mask, int nw, int *err, const uint32_t *jumps) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < ncol) kiss_mask_column(ncol, nlay, nsub, icld, seed, play, cldfr, mask, nw, err, col);
+  if (col < ncol) kiss_mask_jump(ncol, nlay, icld, play, cldfr, mask, nw, err, jumps, col, blockIdx.y);
+}
+
+// Jump operators of (nsub, nlay, icld, seed) on the device; rebuilt and uploaded only when the key changes.
+// which: 0 shortwave, 1 longwave (separate buffers: the two may be in flight on different streams).
+static const uint32_t *kiss_jumps_device(rrtmg_ctx *ctx, int which, int nsub, int nlay, int icld, int seed, hipStream_t s) {
+  const int key[4] = {nsub, nlay, icld, seed};
+  uint32_t *dev = (uint32_t *)ctx->buf(which == 0 ? "sw.w.kissjump" : "lw.w.kissjump", (size_t)nsub * kKissJumpWords * sizeof(uint32_t));
+  if (!dev) return nullptr;
+  bool same = ctx->kiss_dev[which] == dev;
+  for (int i = 0; i < 4; ++i) same = same && ctx->kiss_key[which][i] == key[i];
+  if (!same) {
+    (void)hipStreamSynchronize(s);   // the host copy below may still be the source of an earlier upload
+    kiss_build_jumps(nsub, nlay, icld, seed, ctx->kiss_host[which]);
+    if (hipMemcpyAsync(dev, ctx->kiss_host[which].data(), ctx->kiss_host[which].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
+      ctx->fail(RRTMG_ERR_HIP, "upload of the KISS jump table failed");
+      return nullptr;
+    }
+    for (int i = 0; i < 4; ++i) ctx->kiss_key[which][i] = key[i];
+    ctx->kiss_dev[which] = dev;
+  }
+  return dev;
 }
 
 // externally supplied cldfmcl [lay][col][nsub] (0/1 doubles) -> bit mask

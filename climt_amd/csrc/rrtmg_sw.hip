@@ -136,7 +136,9 @@ int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(dc, cldfrac, nl * 8, hipMemcpyHostToDevice, s));
   RRTMG_HIP_CHECK(ctx, hipMemsetAsync(ctx->err_dev, 0, sizeof(int), s));
   const int ntile = (ncol + 63) / 64;
-  hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile), dim3(64), 0, s, ncol, nlay, nsub, icld, permuteseed, dp, dc, mk, nw, ctx->err_dev);
+  const uint32_t *jumps = kiss_jumps_device(ctx, which == 0 ? 0 : 1, nsub, nlay, icld, permuteseed, s);
+  if (!jumps) return ctx->status;
+  hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, icld, dp, dc, mk, nw, ctx->err_dev, jumps);
   hipLaunchKernelGGL(cldfmcl_from_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, nsub, mk, nw, dm);
   int herr = 0;
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, ctx->err_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -269,7 +271,9 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
         if (!ok) return ctx->status;
         hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, kSwNGpt, cm, d.mask, d.nw);
       } else if (a->irng == 0) {
-        hipLaunchKernelGGL(kiss_mask_kernel, gcol, blk, 0, s, N, L, kSwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err);
+        const uint32_t *jumps = kiss_jumps_device(ctx, 0, kSwNGpt, L, d.icld, a->permuteseed, s);
+        if (!jumps) return ctx->status;
+        hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
       } else {
         std::vector<double> cf(nl);
         if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }

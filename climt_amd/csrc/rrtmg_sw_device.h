@@ -362,49 +362,101 @@ RRTMG_HD double kiss_next(Kiss &k) {
   return (double)kiss * 2.328306e-10 + 0.5;
 }
 
+// seeds of one column from the fractional digits of the four lowest mid-layer pressures (mcica_subcol_gen_sw.f90:340-356)
+RRTMG_HD bool kiss_seed_column(int ncol, const double *play, int *err, int col, Kiss &k) {
+  // integer seeds come from the fractional part of pmid = play*100: the product must be ROUNDED before the
+  // subtraction (as the reference, which stores pmid), so no fused multiply-add here
+#pragma clang fp contract(off)
+  const long N = ncol;
+  const double p1 = play[col] * 1.e2, p2 = play[N + col] * 1.e2;
+  const double p3 = play[2l * N + col] * 1.e2, p4 = play[3l * N + col] * 1.e2;
+  if (p1 < p2) { report_error(err, 14); return false; }
+  k.s1 = (int32_t)((p1 - (double)(int)p1) * 1000000000.0);
+  k.s2 = (int32_t)((p2 - (double)(int)p2) * 1000000000.0);
+  k.s3 = (int32_t)((p3 - (double)(int)p3) * 1000000000.0);
+  k.s4 = (int32_t)((p4 - (double)(int)p4) * 1000000000.0);
+  return true;
+}
+
+// one sub-column of one column from the generator state k positioned at the sub-column's first draw
+RRTMG_HD void kiss_mask_subcolumn(int ncol, int nlay, int icld, const double *cldfr, uint64_t *mask, int nw, int col, int g, Kiss &k) {
+  const int N = ncol, L = nlay;
+  const double cldmin = 1.0e-20;
+  double cdf_prev = 0.0, cmax = 0.0;
+  if (icld == 3) cmax = kiss_next(k);
+  uint64_t word = 0;
+  for (int l = 0; l < L; ++l) {
+    double cf = cldfr[(long)l * N + col];
+    if (cf < cldmin) cf = 0.0;
+    double cdf;
+    if (icld == 3) {
+      cdf = cmax;
+    } else {
+      cdf = kiss_next(k);
+      if (icld == 2 && l > 0) {
+        double cfm = cldfr[(long)(l - 1) * N + col];
+        if (cfm < cldmin) cfm = 0.0;
+        if (cdf_prev > 1.0 - cfm) cdf = cdf_prev; else cdf = cdf * (1.0 - cfm);
+      }
+    }
+    cdf_prev = cdf;
+    if (cdf >= 1.0 - cf) word |= (1ull << (l & 63));
+    if ((l & 63) == 63 || l == L - 1) { mask[((long)g * nw + (l >> 6)) * N + col] = word; word = 0; }
+  }
+}
+
+// Reference order, one thread per column: sub-columns drawn one after the other from ONE stream (this is the
+// definition the jump-ahead kernel below is tested against).
 RRTMG_HD void kiss_mask_column(int ncol, int nlay, int nsub, int icld, int changeSeed, const double *play,
                                const double *cldfr, uint64_t *mask, int nw, int *err, int col) {
   const int N = ncol, L = nlay;
-  const double cldmin = 1.0e-20;
   for (int g = 0; g < nsub; ++g)
     for (int w = 0; w < nw; ++w) mask[((long)g * nw + w) * N + col] = 0ull;
   if (icld == 0) return;
   if (L < 4) { report_error(err, 4); return; }
   Kiss k;
-  {
-    // integer seeds come from the fractional part of pmid = play*100: the product must be ROUNDED before the
-    // subtraction (as the reference, which stores pmid), so no fused multiply-add here
-#pragma clang fp contract(off)
-    const double p1 = play[col] * 1.e2, p2 = play[(long)N + col] * 1.e2;
-    const double p3 = play[2l * N + col] * 1.e2, p4 = play[3l * N + col] * 1.e2;
-    if (p1 < p2) { report_error(err, 14); return; }
-    k.s1 = (int32_t)((p1 - (double)(int)p1) * 1000000000.0);
-    k.s2 = (int32_t)((p2 - (double)(int)p2) * 1000000000.0);
-    k.s3 = (int32_t)((p3 - (double)(int)p3) * 1000000000.0);
-    k.s4 = (int32_t)((p4 - (double)(int)p4) * 1000000000.0);
-  }
+  if (!kiss_seed_column(ncol, play, err, col, k)) return;
   for (int i = 0; i < changeSeed; ++i) (void)kiss_next(k);
-  for (int g = 0; g < nsub; ++g) {
-    double cdf_prev = 0.0, cmax = 0.0;
-    if (icld == 3) cmax = kiss_next(k);
-    for (int l = 0; l < L; ++l) {
-      double cf = cldfr[(long)l * N + col];
-      if (cf < cldmin) cf = 0.0;
-      double cdf;
-      if (icld == 3) {
-        cdf = cmax;
-      } else {
-        cdf = kiss_next(k);
-        if (icld == 2 && l > 0) {
-          double cfm = cldfr[(long)(l - 1) * N + col];
-          if (cfm < cldmin) cfm = 0.0;
-          if (cdf_prev > 1.0 - cfm) cdf = cdf_prev; else cdf = cdf * (1.0 - cfm);
-        }
-      }
-      cdf_prev = cdf;
-      if (cdf >= 1.0 - cf) mask[((long)g * nw + (l >> 6)) * N + col] |= (1ull << (l & 63));
-    }
-  }
+  for (int g = 0; g < nsub; ++g) kiss_mask_subcolumn(ncol, nlay, icld, cldfr, mask, nw, col, g, k);
+}
+
+// ---- jump-ahead: sub-column g starts n_g = changeSeed + g * (draws per sub-column) draws into the column's
+// stream.  The four component generators of KISS can each be advanced n steps in closed form:
+//   congruential  x -> 69069 x + 1327217885 (mod 2^32)      : affine map (A_n, C_n)
+//   xorshift      13 / 17 / 5                                 : 32x32 matrix over GF(2), M^n (32 column words)
+//   multiply-with-carry  s -> a (s & 65535) + (s >> 16)       : after two real steps s lies in [0, m], m = a 2^16 - 1,
+//                                                               and the step is s -> a s mod m (fixed points 0 and m)
+// so one thread per (column, sub-column) reproduces the reference's sequential stream exactly.  The per-sub-column
+// jump operators are the same for every column; the host builds them (rrtmg_kiss_host.h) -- kKissJumpWords words
+// per sub-column: [0] n, [1] A_n, [2] C_n, [3] 18000^(n-2) mod m3, [4] 30903^(n-2) mod m4, [8..39] columns of M^n.
+constexpr int kKissJumpWords = 40;
+constexpr uint32_t kKissM3 = 18000u * 65536u - 1u, kKissM4 = 30903u * 65536u - 1u;
+RRTMG_HD uint32_t kiss_mwc_jump(uint32_t s, uint32_t a, uint32_t m, uint32_t n, uint32_t apow) {
+  const uint32_t real = n < 2u ? n : 2u;
+  for (uint32_t i = 0; i < real; ++i) s = a * (s & 65535u) + (s >> 16);
+  if (n > 2u && s != 0u && s != m) s = (uint32_t)(((uint64_t)s * (uint64_t)apow) % (uint64_t)m);
+  return s;
+}
+RRTMG_HD void kiss_jump(Kiss &k, const uint32_t *J) {
+  const uint32_t n = J[0];
+  uint32_t a = (uint32_t)k.s1, b = (uint32_t)k.s2;
+  a = J[1] * a + J[2];
+  uint32_t r = 0;
+  for (int i = 0; i < 32; ++i) r ^= ((b >> i) & 1u) ? J[8 + i] : 0u;
+  k.s1 = (int32_t)a; k.s2 = (int32_t)r;
+  k.s3 = (int32_t)kiss_mwc_jump((uint32_t)k.s3, 18000u, kKissM3, n, J[3]);
+  k.s4 = (int32_t)kiss_mwc_jump((uint32_t)k.s4, 30903u, kKissM4, n, J[4]);
+}
+// one thread per (column, sub-column)
+RRTMG_HD void kiss_mask_jump(int ncol, int nlay, int icld, const double *play, const double *cldfr, uint64_t *mask, int nw,
+                             int *err, const uint32_t *jumps, int col, int g) {
+  for (int w = 0; w < nw; ++w) mask[((long)g * nw + w) * ncol + col] = 0ull;
+  if (icld == 0) return;
+  if (nlay < 4) { report_error(err, 4); return; }
+  Kiss k;
+  if (!kiss_seed_column(ncol, play, err, col, k)) return;
+  kiss_jump(k, jumps + (long)g * kKissJumpWords);
+  kiss_mask_subcolumn(ncol, nlay, icld, cldfr, mask, nw, col, g, k);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 
 #include "../../climt_amd/csrc/rrtmg_sw_device.h"
 #include "../../climt_amd/csrc/rrtmg_sw_host.h"
+#include "../../climt_amd/csrc/rrtmg_kiss_host.h"
 #include "../../include/rrtmg_hip.h"
 
 using namespace rrtmg;
@@ -118,6 +119,12 @@ extern "C" int emu_mask(int which, int ncol, int nlay, int icld, int seed, int i
   std::vector<uint64_t> mask((size_t)nsub * nw * ncol, 0);
   int err = 0;
   if (irng == 0) { for (int c = 0; c < ncol; ++c) kiss_mask_column(ncol, nlay, nsub, icld, seed, play, cldfr, mask.data(), nw, &err, c); }
+  else if (irng == -1) {
+    // the device kernel's decomposition: one (column, sub-column) at a time through the jump-ahead operators
+    std::vector<uint32_t> jumps;
+    kiss_build_jumps(nsub, nlay, icld, seed, jumps);
+    for (int g = 0; g < nsub; ++g) for (int c = 0; c < ncol; ++c) kiss_mask_jump(ncol, nlay, icld, play, cldfr, mask.data(), nw, &err, jumps.data(), c, g);
+  }
   else mt_mask_host(ncol, nlay, nsub, icld, seed, cldfr, mask, nw);
   for (int l = 0; l < nlay; ++l) for (int c = 0; c < ncol; ++c) for (int g = 0; g < nsub; ++g)
     cldfmcl[((size_t)l * ncol + c) * nsub + g] = ((mask[((size_t)g * nw + (l >> 6)) * ncol + c] >> (l & 63)) & 1ull) ? 1.0 : 0.0;
