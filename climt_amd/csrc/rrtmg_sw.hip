@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   const int item = T.item[T.sched[k]], slot = T.sched[k];
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63);
+  double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item(d, T, sh_exp, item, col, scr, 64, sink);
 }

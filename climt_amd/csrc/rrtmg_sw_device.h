@@ -911,10 +911,12 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
     }
     c.any_cloudy |= c.cloudy[g];
   }
+  // scratch slab of this (tile, item): [layer][field][lane][G] -- the G values of a lane are one 16-byte access;
+  // scr points at this lane's first element, stride = lanes per row (64 on the device, 1 in the host emulation)
 #ifdef RRTMG_ABL_NOSCRATCH
-  auto S = [&](int f, int l, int g) -> double & { (void)l; return scr[(((long)0 * F_NTOT + f) * G + g) * stride]; };
+  auto SP = [&](int f, int l) -> double * { (void)l; return scr + ((long)0 * F_NTOT + f) * stride * G; };
 #else
-  auto S = [&](int f, int l, int g) -> double & { return scr[(((long)l * F_NTOT + f) * G + g) * stride]; };
+  auto SP = [&](int f, int l) -> double * { return scr + ((long)l * F_NTOT + f) * stride * G; };
 #endif
 
   // ---- sweep 1: bottom -> top, upward adding recurrence (rrtmg_sw_vrtqdr.f90:114-140) ---------------
@@ -932,13 +934,22 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
         const double nrupd = oc[g].refd + oc[g].trad * oc[g].trad * rupdc[g] * zr;
         rupc[g] = nrup; rupdc[g] = nrupd;
       }
-      S(F_RUP, l, g) = rupc[g]; S(F_RUPD, l, g) = rupdc[g];
       if (c.cloudy[g]) {
         const double zr = qrcp(1.0 - rupd[g] * ot[g].refd);
         const double nrup = ot[g].ref + (ot[g].trad * ((ot[g].tra - ot[g].dbt) * rupd[g] + ot[g].dbt * rup[g])) * zr;
         const double nrupd = ot[g].refd + ot[g].trad * ot[g].trad * rupd[g] * zr;
         rup[g] = nrup; rupd[g] = nrupd;
-        S(F_NCLR + F_RUP, l, g) = rup[g]; S(F_NCLR + F_RUPD, l, g) = rupd[g];
+      }
+    }
+    {
+      V<G> v0, v1;
+#pragma unroll
+      for (int g = 0; g < G; ++g) { v0[g] = rupc[g]; v1[g] = rupdc[g]; }
+      vstore<G>(SP(F_RUP, l), v0); vstore<G>(SP(F_RUPD, l), v1);
+      if (c.any_cloudy) {
+#pragma unroll
+        for (int g = 0; g < G; ++g) { v0[g] = rup[g]; v1[g] = rupd[g]; }
+        vstore<G>(SP(F_NCLR + F_RUP, l), v0); vstore<G>(SP(F_NCLR + F_RUPD, l), v1);
       }
     }
   }
@@ -949,17 +960,23 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   for (int g = 0; g < G; ++g) { tdnc[g] = 1.0; rdndc[g] = 0.0; tdbtc[g] = 1.0; tdn[g] = 1.0; rdnd[g] = 0.0; tdbt[g] = 1.0; }
   for (int lev = L; lev >= 0; --lev) {
     double sfu = 0.0, sfd = 0.0, scu = 0.0, scd = 0.0;
+    // (fetching these rows a level ahead costs more in registers than the latency it hides: measured)
+    V<G> c_rc, c_rdc, c_r, c_rd;
+    if (lev > 0) {
+      c_rc = vload<G>(SP(F_RUP, lev - 1)); c_rdc = vload<G>(SP(F_RUPD, lev - 1));
+      if (c.any_cloudy) { c_r = vload<G>(SP(F_NCLR + F_RUP, lev - 1)); c_rd = vload<G>(SP(F_NCLR + F_RUPD, lev - 1)); }
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const double rc = (lev > 0) ? S(F_RUP, lev - 1, g) : albp;
-      const double rdc = (lev > 0) ? S(F_RUPD, lev - 1, g) : albd;
+      const double rc = (lev > 0) ? c_rc[g] : albp;
+      const double rdc = (lev > 0) ? c_rdc[g] : albd;
       double zr = qrcp(1.0 - rdndc[g] * rdc);
       const double cu = (tdbtc[g] * rc + (tdnc[g] - tdbtc[g]) * rdc) * zr;
       const double cd = tdbtc[g] + (tdnc[g] - tdbtc[g] + tdbtc[g] * rc * rdndc[g]) * zr;
       double fu = cu, fd = cd;
       if (c.cloudy[g]) {
-        const double r = (lev > 0) ? S(F_NCLR + F_RUP, lev - 1, g) : albp;
-        const double rd = (lev > 0) ? S(F_NCLR + F_RUPD, lev - 1, g) : albd;
+        const double r = (lev > 0) ? c_r[g] : albp;
+        const double rd = (lev > 0) ? c_rd[g] : albd;
         zr = qrcp(1.0 - rdnd[g] * rd);
         fu = (tdbt[g] * r + (tdn[g] - tdbt[g]) * rd) * zr;
         fd = tdbt[g] + (tdn[g] - tdbt[g] + tdbt[g] * r * rdnd[g]) * zr;
