@@ -754,6 +754,11 @@ RRTMG_HD bool lw_anymask_bit(const LwDev &d, int col, int l) {
   return (d.anymask[(long)(l >> 6) * d.ncol + col] >> (l & 63)) & 1ull;
 }
 
+#ifdef RRTMG_ABL_UNIFORMLOOKUP
+#define LW_TBLIDX(x) (((int)(x)) & 1)
+#else
+#define LW_TBLIDX(x) ((int)(x))
+#endif
 // One (column, work item): rtrn / rtrnmc for the item's G g-points (rrtmg_lw_rtrn.f90:324-525).  The layer
 // state, the species mixtures, the Planck functions and the cloud optics are evaluated once for the G g-points.
 // Radiances leave through `sink` weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543) and summed over
@@ -873,7 +878,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           gassrc = plf * (blay + dplankdn * odepth_rec) * atrans;
           odtot = odepth + odcld;
           const double tblind = odtot / (kBpade + odtot);
-          const int ittot = (int)(kTblInt * tblind + 0.5);
+          const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double tfactot = tfn_tbl[ittot];
           bbdtot = plf * (blay + tfactot * dplankdn);
           bbd = plf * (blay + dplankdn * odepth_rec);
@@ -882,14 +887,14 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbutot = plf * (blay + tfactot * dplankup);
         } else {
           double tblind = odepth / (kBpade + odepth);
-          const int itgas = (int)(kTblInt * tblind + 0.5);
+          const int itgas = LW_TBLIDX(kTblInt * tblind + 0.5);
           odepth = tau_tbl[itgas];
           atrans = 1.0 - exp_tbl[itgas];
           const double tfacgas = tfn_tbl[itgas];
           gassrc = atrans * plf * (blay + tfacgas * dplankdn);
           odtot = odepth + odcld;
           tblind = odtot / (kBpade + odtot);
-          const int ittot = (int)(kTblInt * tblind + 0.5);
+          const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double tfactot = tfn_tbl[ittot];
           bbdtot = plf * (blay + tfactot * dplankdn);
           bbd = plf * (blay + tfacgas * dplankdn);
@@ -908,7 +913,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbugas = plf * (blay + dplankup * odepth);
         } else {
           const double tblind = odepth / (kBpade + odepth);
-          const int itr = (int)(kTblInt * tblind + 0.5);
+          const int itr = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double transc = exp_tbl[itr];
           atrans = 1.0 - transc;
           const double tausfac = tfn_tbl[itr];
