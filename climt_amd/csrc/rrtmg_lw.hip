@@ -1,7 +1,8 @@
 // rrtmg_lw.hip -- longwave kernels and launch sequence (gfx950).
 //
 // Launch sequence of one rrtmg_hip_lw_fluxes call (all on ctx->stream):
-//   lw_prep_kernel       <<<ncol/64>>>          inatm + setcoef per column
+//   lw_prep_layer_kernel <<<ncol/64, nlay>>>    inatm + setcoef per (column, layer)
+//   lw_prep_kernel       <<<ncol/64>>>          column part: laytrop, precipitable water -> secdiff
 //   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
@@ -15,6 +16,10 @@
 
 namespace rrtmg {
 
+__global__ void __launch_bounds__(64) lw_prep_layer_kernel(LwDev d, LwTab T) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_prep_layer(d, T, col, blockIdx.y);
+}
 __global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_prep_column(d, T, col);
@@ -172,6 +177,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
 
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
+  hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
   hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
   if (clouds) {
     if (!d.mcica) {

@@ -89,14 +89,14 @@ RRTMG_HD size_t lw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) /
 // ------------------------------------------------------------------------------------------
 // inatm (rrtmg_lw_rad.nomcica.f90:744-880) + setcoef indices (rrtmg_lw_setcoef.f90:253-411)
 // ------------------------------------------------------------------------------------------
-RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
+// layer part: one thread per (column, layer)
+RRTMG_HD void lw_prep_layer(const LwDev &d, const LwTab &T, int col, int l) {
   const int L = d.nlay, N = d.ncol;
   const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
   const double amd = 28.9660, amw = 18.0160;
   const double stpfac = 296.0 / 1013.0;
-  int laytrop = 0;
-  double amttl = 0.0, wvttl = 0.0;
-  for (int l = 0; l < L; ++l) {
+  int laytrop = 0;   // 1 if this layer is in the lower atmosphere
+  {
     const long i = (long)l * N + col;
     const double pz0 = d.plev[i], pz1 = d.plev[i + N];
     const double pavel = d.play[i], tavel = d.tlay[i];
@@ -108,8 +108,6 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
     summol = summol + v2; summol = summol + v3; summol = summol + v4; summol = summol + 0.0; summol = summol + v6; summol = summol + v7;
     const double wbroad = coldry * (1.0 - summol);
     const double w1 = coldry * v1, w2 = coldry * v2, w3 = coldry * v3, w4 = coldry * v4, w5 = coldry * 0.0, w6 = coldry * v6, w7 = coldry * v7;
-    amttl = amttl + coldry + w1;
-    wvttl = wvttl + w1;
     double *q = d.prep + lw_prep_off(L, col, l);
     q[LP_WX1 * 64] = coldry * (d.ccl4 ? d.ccl4[i] : 0.0) * 1.e-20;
     q[LP_WX2 * 64] = coldry * (d.cfc11 ? d.cfc11[i] : 0.0) * 1.e-20;
@@ -174,7 +172,25 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
     q[LP_COLH2O * 64] = colh2o; q[LP_COLCO2 * 64] = colco2; q[LP_COLO3 * 64] = colo3; q[LP_COLN2O * 64] = coln2o;
     q[LP_COLCO * 64] = colco; q[LP_COLCH4 * 64] = colch4; q[LP_COLO2 * 64] = colo2; q[LP_COLBRD * 64] = colbrd;
     q[LP_COLDRY * 64] = coldry; q[LP_PAVEL * 64] = pavel;
-    q[LP_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24));
+    // bit 30: layer is in the lower atmosphere (counted into laytrop by the column part)
+    q[LP_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24) | (laytrop << 30));
+  }
+}
+
+// column part (after every layer of the column is done): laytrop, precipitable water -> diffusivity angle by band
+RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
+  (void)T;
+  const int L = d.nlay, N = d.ncol;
+  const double amd = 28.9660, amw = 18.0160;
+  int laytrop = 0;
+  double amttl = 0.0, wvttl = 0.0;
+  for (int l = 0; l < L; ++l) {
+    const double *q = d.prep + lw_prep_off(L, col, l);
+    laytrop += ((int)q[LP_IDX * 64] >> 30) & 1;
+    const double coldry = q[LP_COLDRY * 64];
+    const double w1 = coldry * d.h2o[(long)l * N + col];
+    amttl = amttl + coldry + w1;
+    wvttl = wvttl + w1;
   }
   d.laytrop[col] = laytrop;
   const double wvsh = (amw * wvttl) / (amd * amttl);

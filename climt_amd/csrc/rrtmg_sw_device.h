@@ -104,14 +104,14 @@ RRTMG_HD size_t sw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) /
 // ------------------------------------------------------------------------------------------
 // inatm_sw (rrtmg_sw_rad.nomcica.f90:1441-1465) + setcoef_sw (rrtmg_sw_setcoef.f90:137-303)
 // ------------------------------------------------------------------------------------------
-RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
+// layer part: one thread per (column, layer)
+RRTMG_HD void sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
   const int L = d.nlay, N = d.ncol;
   const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
   const double amd = 28.9660, amw = 18.0160;
   const double stpfac = 296.0 / 1013.0;
-  int laytrop = 0;
-  int anycld = 0;
-  for (int l = 0; l < L; ++l) {
+  int lower = 0;
+  {
     const long i = (long)l * N + col;
     const double pz0 = d.plev[i], pz1 = d.plev[i + N];
     const double pavel = d.play[i], tavel = d.tlay[i];
@@ -138,7 +138,7 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
     int indself, indfor;
     double forfac, forfrac, selffac, selffrac;
     if (plog > 4.56) {
-      laytrop++;
+      lower = 1;
       forfac = scalefac / (1. + water);
       double factor = (332.0 - tavel) / 36.0;
       int ifac = (int)factor;
@@ -173,13 +173,24 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
     q[P_SELFFAC * 64] = selffac; q[P_SELFFRAC * 64] = selffrac; q[P_FORFAC * 64] = forfac; q[P_FORFRAC * 64] = forfrac;
     q[P_COLH2O * 64] = colh2o; q[P_COLCO2 * 64] = colco2; q[P_COLO3 * 64] = colo3; q[P_COLCH4 * 64] = colch4;
     q[P_COLO2 * 64] = colo2; q[P_COLMOL * 64] = colmol;
-    q[P_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24));
+    // bit 28: layer is in the lower atmosphere (counted into laytrop by the column part)
+    q[P_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24) | (lower << 28));
     if (d.icld >= 1 && d.cldfr) {
       const double cf = d.cldfr[i];
-      if (cf > 0.0) anycld = 1;
       // rrtmg_sw_rad.nomcica.f90:616-620
       if (!d.mcica && cf > 1.e-6 && cf < 1.0 - 1.e-6) report_error(d.err, 10);
     }
+  }
+}
+
+// column part (after every layer of the column is done): laytrop, cloud flag, zenith angle, solar-source layers
+RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
+  (void)T;
+  const int L = d.nlay, N = d.ncol;
+  int laytrop = 0, anycld = 0;
+  for (int l = 0; l < L; ++l) {
+    laytrop += ((int)d.prep[sw_prep_off(L, col, l) + P_IDX * 64] >> 28) & 1;
+    if (d.icld >= 1 && d.cldfr && d.cldfr[(long)l * N + col] > 0.0) anycld = 1;
   }
   d.laytrop[col] = laytrop;
   d.anycld[col] = anycld;
@@ -569,7 +580,7 @@ RRTMG_HD void sw_load_layer(const SwDev &d, int col, int lay, SwLayerIn &s) {
   s.colh2o = q[P_COLH2O * 64]; s.colco2 = q[P_COLCO2 * 64]; s.colo3 = q[P_COLO3 * 64]; s.colch4 = q[P_COLCH4 * 64];
   s.colo2 = q[P_COLO2 * 64]; s.colmol = q[P_COLMOL * 64];
   const int p = (int)q[P_IDX * 64];
-  s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xff; s.indfor = (p >> 24) & 0xff;
+  s.jp = p & 0xff; s.jt = (p >> 8) & 0xf; s.jt1 = (p >> 12) & 0xf; s.indself = (p >> 16) & 0xff; s.indfor = (p >> 24) & 0xf;
 }
 
 struct SwSpec { int js; double fs; double speccomb; };

@@ -66,7 +66,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   d.duflx_dt = a->duflx_dt; d.duflxc_dt = a->duflxc_dt;
   int errflag = 0;
   d.err = &errflag;
-  for (int c = 0; c < N; ++c) lw_prep_column(d, T, c);
+  for (int c = 0; c < N; ++c) { for (int l = 0; l < L; ++l) lw_prep_layer(d, T, c, l); lw_prep_column(d, T, c); }
   if (clouds) {
     if (!d.mcica) {
       for (int c = 0; c < N; ++c) lw_cloud_column(d, T, c);
@@ -135,6 +135,7 @@ extern "C" int emu_lw_taumol(const rrtmg_lw_args *a, const char *blob_path, doub
   d.laytrop = laytrop.data();
   int errflag = 0;
   d.err = &errflag;
+  for (int l = 0; l < L; ++l) lw_prep_layer(d, T, 0, l);
   lw_prep_column(d, T, 0);
   emu_taug_band<1>(d, T, taug, fracs); emu_taug_band<2>(d, T, taug, fracs); emu_taug_band<3>(d, T, taug, fracs); emu_taug_band<4>(d, T, taug, fracs);
   emu_taug_band<5>(d, T, taug, fracs); emu_taug_band<6>(d, T, taug, fracs); emu_taug_band<7>(d, T, taug, fracs); emu_taug_band<8>(d, T, taug, fracs);

@@ -73,7 +73,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   int errflag = 0;
   d.err = &errflag;
-  for (int c = 0; c < N; ++c) sw_prep_column(d, T, c);
+  for (int c = 0; c < N; ++c) { for (int l = 0; l < L; ++l) sw_prep_layer(d, T, c, l); sw_prep_column(d, T, c); }
   std::vector<double> ta, om, as;
   if (d.iaer == 6) {
     ta.assign(nl * kSwNBand, 0); om.assign(nl * kSwNBand, 0); as.assign(nl * kSwNBand, 0);
