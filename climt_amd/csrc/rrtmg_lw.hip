@@ -23,6 +23,12 @@ __global__ void __launch_bounds__(64) lw_prep_layer_kernel(LwDev d, LwTab T) {
 __global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_prep_column(d, T, col);
+  // tile flag: does any column of this 64-column tile have a cloud? (selects the solve kernel variant)
+  bool cld = false;
+  if (col < d.ncol && d.icld >= 1 && d.cldfr)
+    for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(long)l * d.ncol + col] > 0.0;
+  const unsigned long long any = __ballot(cld);
+  if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
 }
 __global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -47,15 +53,18 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 #ifndef RRTMG_LW_WAVES
 #define RRTMG_LW_WAVES 2
 #endif
+// Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
+template <bool CLD>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile) {
   const int q = blockIdx.x;
   const int tile = q % ntile, k = q / ntile;
+  if ((d.tile_cld[tile] != 0) != CLD) return;
   const int slot = T.sched[k], item = T.item[slot];
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
   LwPartSink sink = lw_part_sink(d, slot, col);
-  lw_solve_item(d, T, item, col, scr, 64, sink);
+  lw_solve_item<CLD>(d, T, item, col, scr, 64, sink);
 }
 
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
@@ -150,7 +159,8 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.secdiff = wd("secdiff", (size_t)N * 16);
   d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
   d.ncbands = (int32_t *)ctx->buf("lw.w.ncbands", (size_t)N * 4);
-  if (!d.laytrop || !d.ncbands) ok = false;
+  d.tile_cld = (int32_t *)ctx->buf("lw.w.tilecld", (size_t)((N + 63) / 64) * 4);
+  if (!d.laytrop || !d.ncbands || !d.tile_cld) ok = false;
   if (clouds) d.ctau = wd("ctau", nl * 16);
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) {
@@ -205,7 +215,8 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     }
   }
   (void)hipEventRecord(ctx->ev[1][0], s);
-  hipLaunchKernelGGL(lw_solve_all_kernel, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  hipLaunchKernelGGL(lw_solve_all_kernel<false>, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  if (clouds) hipLaunchKernelGGL(lw_solve_all_kernel<true>, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
   (void)hipEventRecord(ctx->ev[1][1], s);
   ctx->ev_valid[1] = true;
   hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);

@@ -66,6 +66,7 @@ struct LwDev {
   // clouds
   double *ctau;        // [16][lay][col]  (nomcica: taucloud(lay, ib); mcica: per-band cloudy-sub-column tau)
   int32_t *ncbands;    // [col]
+  int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has cldfr > 0 (selects the solve kernel variant)
   uint64_t *mask;      // [140][nw][col]
   uint64_t *anymask;   // [nw][col]   OR over the sub-columns (icldlyr of rtrnmc)
   int nw;
@@ -779,7 +780,8 @@ RRTMG_HD bool lw_anymask_bit(const LwDev &d, int col, int l) {
 // state, the species mixtures, the Planck functions and the cloud optics are evaluated once for the G g-points.
 // Radiances leave through `sink` weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543) and summed over
 // the item's g-points in g-point order.
-template <int BAND, int G, class Sink>
+// CLD = false: the caller guarantees a cloud-free column (the cloud code is compiled out).
+template <int BAND, int G, bool CLD, class Sink>
 RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
   const int ib = BAND - 1;
@@ -800,7 +802,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   auto W = [&](double r) { return (r * wtdiff) * delw; };
 
   // cloud bookkeeping
-  const bool clouds = d.icld >= 1 && d.cldfr != nullptr;
+  const bool clouds = CLD && d.icld >= 1 && d.cldfr != nullptr;
   int cb = 0;           // cloud band index used for odcld / efclfrac (non-McICA)
   double secd_cb = secd;
   if (clouds && !d.mcica) {
@@ -1045,34 +1047,34 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 }
 
 // Dispatch of one work item (packed, see LwTab) for one column: band switch + G in {4, 2}.
-template <int BAND, class Sink>
+template <int BAND, bool CLD, class Sink>
 RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
   constexpr int ng = kLwNg[BAND - 1];
   if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
-    if (g == 4) { lw_solve_thread<BAND, 4>(d, T, col, ig0, scr, stride, sink); return; }
+    if (g == 4) { lw_solve_thread<BAND, 4, CLD>(d, T, col, ig0, scr, stride, sink); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2>(d, T, col, ig0, scr, stride, sink);
+  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD>(d, T, col, ig0, scr, stride, sink);
 }
-template <class Sink>
+template <bool CLD, class Sink>
 RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, double *scr, long stride, Sink &sink) {
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
   switch ((item & 0xff) + 1) {
-    case 1: lw_solve_band<1>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 2: lw_solve_band<2>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 3: lw_solve_band<3>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 4: lw_solve_band<4>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 5: lw_solve_band<5>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 6: lw_solve_band<6>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 7: lw_solve_band<7>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 8: lw_solve_band<8>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 9: lw_solve_band<9>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 10: lw_solve_band<10>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 11: lw_solve_band<11>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 12: lw_solve_band<12>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 13: lw_solve_band<13>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 14: lw_solve_band<14>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 15: lw_solve_band<15>(d, T, g, col, ig0, scr, stride, sink); break;
-    default: lw_solve_band<16>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 1: lw_solve_band<1, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 2: lw_solve_band<2, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 3: lw_solve_band<3, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 4: lw_solve_band<4, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 5: lw_solve_band<5, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 6: lw_solve_band<6, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 7: lw_solve_band<7, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 8: lw_solve_band<8, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 9: lw_solve_band<9, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 10: lw_solve_band<10, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 11: lw_solve_band<11, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 12: lw_solve_band<12, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 13: lw_solve_band<13, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 14: lw_solve_band<14, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 15: lw_solve_band<15, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    default: lw_solve_band<16, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
   }
 }
 

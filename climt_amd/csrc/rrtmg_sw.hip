@@ -23,6 +23,10 @@ __global__ void __launch_bounds__(64) sw_prep_layer_kernel(SwDev d, SwTab T) {
 __global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) sw_prep_column(d, T, col);
+  // tile flag: does any column of this 64-column tile have a cloud? (selects the solve kernel variant)
+  const bool cld = col < d.ncol && d.anycld[col] != 0;
+  const unsigned long long any = __ballot(cld);
+  if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
 }
 
 __global__ void __launch_bounds__(64) sw_cloud_kernel(SwDev d, SwTab T) {
@@ -78,7 +82,22 @@ constexpr int kSwWgWaves = 1;
 constexpr int kSwWgWaves = RRTMG_SW_WGWAVES;
 #endif
 constexpr int kExpTblN = 10001;
+// Two variants are launched back to back: CLD = false handles the cloud-free tiles with the cloud code compiled
+// out (no spills, more resident wavefronts), CLD = true the tiles flagged by sw_prep_kernel; a wavefront whose
+// tile belongs to the other variant exits at once.
+template <bool CLD>
 __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile) {
+  const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
+  const int q = blockIdx.x;
+  {
+    // workgroup-uniform early exit before the table is staged: none of this group's tiles is ours
+    bool mine = false;
+    for (int w = 0; w < kSwWgWaves; ++w) {
+      const int t = (q % ngrp) * kSwWgWaves + w;
+      if (t < ntile && (d.tile_cld[t] != 0) == CLD) mine = true;
+    }
+    if (!mine) return;
+  }
 #ifdef RRTMG_SW_NOLDS
   const double *sh_exp = T.t + T.exp_tbl;
 #else
@@ -87,15 +106,14 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   __syncthreads();
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
-  const int q = blockIdx.x;
   const int tile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;
+  if (tile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int item = T.item[T.sched[k]], slot = T.sched[k];
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
   SwPartSink sink = sw_part_sink(d, slot, col);
-  sw_solve_item(d, T, sh_exp, item, col, scr, 64, sink);
+  sw_solve_item<CLD>(d, T, sh_exp, item, col, scr, 64, sink);
 }
 
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, int nparts) {
@@ -242,7 +260,8 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   d.pdp = wd("pdp", nl); d.cossza = wd("cossza", N);
   d.laytrop = (int32_t *)ctx->buf("sw.w.laytrop", (size_t)N * 4);
   d.laysolfr = (int32_t *)ctx->buf("sw.w.laysolfr", (size_t)N * 4 * kSwNBand); d.anycld = (int32_t *)ctx->buf("sw.w.anycld", (size_t)N * 4);
-  if (!d.laytrop || !d.laysolfr || !d.anycld) ok = false;
+  d.tile_cld = (int32_t *)ctx->buf("sw.w.tilecld", (size_t)((N + 63) / 64) * 4);
+  if (!d.laytrop || !d.laysolfr || !d.anycld || !d.tile_cld) ok = false;
   if (clouds) { d.ctau = wd("ctau", nl * kSwNBand); d.cssa = wd("cssa", nl * kSwNBand); d.casm = wd("casm", nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
@@ -292,7 +311,11 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     }
   }
   (void)hipEventRecord(ctx->ev[0][0], s);
-  hipLaunchKernelGGL(sw_solve_all_kernel, dim3((ntile + kSwWgWaves - 1) / kSwWgWaves * T.nitem), dim3(64 * kSwWgWaves), 0, s, d, T, ntile);
+  {
+    const dim3 grid((ntile + kSwWgWaves - 1) / kSwWgWaves * T.nitem), wg(64 * kSwWgWaves);
+    hipLaunchKernelGGL(sw_solve_all_kernel<false>, grid, wg, 0, s, d, T, ntile);
+    if (clouds) hipLaunchKernelGGL(sw_solve_all_kernel<true>, grid, wg, 0, s, d, T, ntile);
+  }
   (void)hipEventRecord(ctx->ev[0][1], s);
   ctx->ev_valid[0] = true;
   hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T.nitem);

@@ -78,7 +78,8 @@ struct SwDev {
   double *prep;
   int32_t *laytrop;    // [col]
   int32_t *laysolfr;   // [14][col], 1-based layer, 0 = source never set
-  int32_t *anycld;     // [col] nomcica: 1 if any layer has cldfr > 0
+  int32_t *anycld;     // [col] 1 if any layer has cldfr > 0
+  int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has a cloud (selects the solve kernel variant)
   double *cossza;      // [col]
   double *pdp;         // [lay][col]
   double *ctau, *cssa, *casm;   // delta-scaled cloud optics [14][lay][col]
@@ -808,7 +809,7 @@ RRTMG_HD bool sw_mask_bit(const SwDev &d, int iw, int col, int l) {
 // adding-method sweeps need.  The layer state, the species mixture, the interpolation weights and the table
 // rows are evaluated ONCE for the G g-points.  Called in BOTH sweeps: recomputing it is cheaper than spilling
 // five more level arrays per g-point through HBM (profiles/r01_pmc_*.txt).
-template <int BAND, int G>
+template <int BAND, int G, bool CLD>
 RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<G> &c, int col, int l,
                               SwLayerOpt (&clr)[G], SwLayerOpt (&tot)[G]) {
   const int L = d.nlay, N = d.ncol;
@@ -825,7 +826,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
   // band cloud optics of this layer (shared by the g-points)
   double zcloud = 0.0, ptauc = 0.0, pomgc = 0.0, pasyc = 0.0;
   bool lcld_band = false;
-  if (c.any_cloudy) {
+  if (CLD && c.any_cloudy) {
     if (!d.mcica) { zcloud = d.cldfr[i]; lcld_band = zcloud > 1.e-12; }
     ptauc = d.ctau[o];
     pomgc = d.cssa[o]; pasyc = d.casm[o];
@@ -852,7 +853,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
       sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, clr[g].ref, clr[g].refd, clr[g].tra, clr[g].trad);
     }
     clr[g].dbt = sw_dbt(exp_tbl, ztauc, rmu0);
-    if (!c.cloudy[g]) continue;
+    if (!CLD || !c.cloudy[g]) continue;
     tot[g] = clr[g];
     bool lcld;
     double zc;
@@ -891,7 +892,8 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
 // [layer][field][G][stride] slab holding the upward-sweep results (rup, rupd) for the clear and -- in cloudy
 // (sub-)columns -- the total sky.  The weighted fluxes of the G g-points are added in g-point order before they
 // leave through `sink`.
-template <int BAND, int G, class Sink>
+// CLD = false: the caller guarantees a cloud-free column (the cloud code is compiled out: fewer registers).
+template <int BAND, int G, bool CLD, class Sink>
 RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_tbl, int col, int ig0, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
   SwThreadCtx<G> c;
@@ -913,7 +915,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     c.cloudy[g] = false;
-    if (d.icld >= 1) {
+    if (CLD && d.icld >= 1) {
       if (d.mcica) {
         for (int w = 0; w < d.nw; ++w) c.cloudy[g] |= (d.mask[((long)(c.iw0 + g) * d.nw + w) * N + col] != 0);
       } else {
@@ -936,7 +938,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   for (int g = 0; g < G; ++g) { rupc[g] = albp; rupdc[g] = albd; rup[g] = albp; rupd[g] = albd; }
   for (int l = 0; l < L; ++l) {
     SwLayerOpt oc[G], ot[G];
-    sw_layer_optics<BAND, G>(d, T, c, col, l, oc, ot);
+    sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, oc, ot);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       {
@@ -945,7 +947,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
         const double nrupd = oc[g].refd + oc[g].trad * oc[g].trad * rupdc[g] * zr;
         rupc[g] = nrup; rupdc[g] = nrupd;
       }
-      if (c.cloudy[g]) {
+      if (CLD && c.cloudy[g]) {
         const double zr = qrcp(1.0 - rupd[g] * ot[g].refd);
         const double nrup = ot[g].ref + (ot[g].trad * ((ot[g].tra - ot[g].dbt) * rupd[g] + ot[g].dbt * rup[g])) * zr;
         const double nrupd = ot[g].refd + ot[g].trad * ot[g].trad * rupd[g] * zr;
@@ -957,7 +959,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
       for (int g = 0; g < G; ++g) { v0[g] = rupc[g]; v1[g] = rupdc[g]; }
       vstore<G>(SP(F_RUP, l), v0); vstore<G>(SP(F_RUPD, l), v1);
-      if (c.any_cloudy) {
+      if (CLD && c.any_cloudy) {
 #pragma unroll
         for (int g = 0; g < G; ++g) { v0[g] = rup[g]; v1[g] = rupd[g]; }
         vstore<G>(SP(F_NCLR + F_RUP, l), v0); vstore<G>(SP(F_NCLR + F_RUPD, l), v1);
@@ -975,7 +977,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
     V<G> c_rc, c_rdc, c_r, c_rd;
     if (lev > 0) {
       c_rc = vload<G>(SP(F_RUP, lev - 1)); c_rdc = vload<G>(SP(F_RUPD, lev - 1));
-      if (c.any_cloudy) { c_r = vload<G>(SP(F_NCLR + F_RUP, lev - 1)); c_rd = vload<G>(SP(F_NCLR + F_RUPD, lev - 1)); }
+      if (CLD && c.any_cloudy) { c_r = vload<G>(SP(F_NCLR + F_RUP, lev - 1)); c_rd = vload<G>(SP(F_NCLR + F_RUPD, lev - 1)); }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -985,7 +987,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
       const double cu = (tdbtc[g] * rc + (tdnc[g] - tdbtc[g]) * rdc) * zr;
       const double cd = tdbtc[g] + (tdnc[g] - tdbtc[g] + tdbtc[g] * rc * rdndc[g]) * zr;
       double fu = cu, fd = cd;
-      if (c.cloudy[g]) {
+      if (CLD && c.cloudy[g]) {
         const double r = (lev > 0) ? c_r[g] : albp;
         const double rd = (lev > 0) ? c_rd[g] : albd;
         zr = qrcp(1.0 - rdnd[g] * rd);
@@ -1006,7 +1008,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
       for (int g = 0; g < G; ++g) { oc[g].ref = 0.1 + 1e-3 * l; oc[g].refd = 0.1; oc[g].tra = 0.8; oc[g].trad = 0.8; oc[g].dbt = 0.7; ot[g] = oc[g]; }
 #else
-      sw_layer_optics<BAND, G>(d, T, c, col, l, oc, ot);
+      sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, oc, ot);
 #endif
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -1016,7 +1018,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
           const double nrdnd = oc[g].refd + oc[g].trad * oc[g].trad * rdndc[g] * zr;
           tdnc[g] = ntdn; rdndc[g] = nrdnd; tdbtc[g] = oc[g].dbt * tdbtc[g];
         }
-        if (c.cloudy[g]) {
+        if (CLD && c.cloudy[g]) {
           const double zr = qrcp(1.0 - ot[g].refd * rdnd[g]);
           const double ntdn = tdbt[g] * ot[g].tra + (ot[g].trad * ((tdn[g] - tdbt[g]) + tdbt[g] * ot[g].ref * rdnd[g])) * zr;
           const double nrdnd = ot[g].refd + ot[g].trad * ot[g].trad * rdnd[g] * zr;
@@ -1028,32 +1030,32 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 }
 
 // Dispatch of one work item (packed, see SwTab) for one column: band switch + G in {4, 2}.
-template <int BAND, class Sink>
+template <int BAND, bool CLD, class Sink>
 RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
   constexpr int ng = SwBandCfg<BAND>::ng;
   if constexpr (ng >= 4 && RRTMG_GMAX >= 4) {
-    if (g == 4) { sw_solve_thread<BAND, 4>(d, T, exp_tbl, col, ig0, scr, stride, sink); return; }
+    if (g == 4) { sw_solve_thread<BAND, 4, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_GMAX < 4) sw_solve_thread<BAND, 2>(d, T, exp_tbl, col, ig0, scr, stride, sink);
+  if constexpr (ng % 4 != 0 || RRTMG_GMAX < 4) sw_solve_thread<BAND, 2, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink);
 }
-template <class Sink>
+template <bool CLD, class Sink>
 RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tbl, int item, int col, double *scr, long stride, Sink &sink) {
   const int g = item_g(item), ig0 = item_ig0(item);
   switch (item_band(item) + 16) {
-    case 16: sw_solve_band<16>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 17: sw_solve_band<17>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 18: sw_solve_band<18>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 19: sw_solve_band<19>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 20: sw_solve_band<20>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 21: sw_solve_band<21>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 22: sw_solve_band<22>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 23: sw_solve_band<23>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 24: sw_solve_band<24>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 25: sw_solve_band<25>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 26: sw_solve_band<26>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 27: sw_solve_band<27>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 28: sw_solve_band<28>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    default: sw_solve_band<29>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 16: sw_solve_band<16, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 17: sw_solve_band<17, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 18: sw_solve_band<18, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 19: sw_solve_band<19, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 20: sw_solve_band<20, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 21: sw_solve_band<21, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 22: sw_solve_band<22, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 23: sw_solve_band<23, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 24: sw_solve_band<24, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 25: sw_solve_band<25, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 26: sw_solve_band<26, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 27: sw_solve_band<27, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 28: sw_solve_band<28, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    default: sw_solve_band<29, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
   }
 }
 

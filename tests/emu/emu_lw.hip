@@ -20,7 +20,11 @@ static void emu_lw_solve(const LwDev &d, const LwTab &T) {
   for (int slot = 0; slot < T.nitem; ++slot)
     for (int col = 0; col < d.ncol; ++col) {
       LwPartSink sink = lw_part_sink(d, slot, col);
-      lw_solve_item(d, T, T.item[slot], col, scr.data(), 1, sink);
+      // the clear-sky variant for cloud-free columns, as the device picks it per tile
+      bool cld = false;
+      if (d.icld >= 1 && d.cldfr) for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(size_t)l * d.ncol + col] > 0.0;
+      if (cld) lw_solve_item<true>(d, T, T.item[slot], col, scr.data(), 1, sink);
+      else lw_solve_item<false>(d, T, T.item[slot], col, scr.data(), 1, sink);
     }
 }
 

@@ -26,7 +26,9 @@ static void emu_solve(const SwDev &d, const SwTab &T) {
   for (int slot = 0; slot < T.nitem; ++slot)
     for (int col = 0; col < d.ncol; ++col) {
       SwPartSink sink = sw_part_sink(d, slot, col);
-      sw_solve_item(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
+      // the clear-sky variant for cloud-free columns, as the device picks it per tile
+      if (d.anycld[col]) sw_solve_item<true>(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
+      else sw_solve_item<false>(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
     }
 }
 
