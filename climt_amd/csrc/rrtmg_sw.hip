@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;
   if (tile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
-  const int item = T.item[T.sched[k]], slot = T.sched[k];
+  const int item = T.item[CLD ? 1 : 0][T.sched[CLD ? 1 : 0][k]], slot = item_iw0(item) >> 1;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
@@ -267,7 +267,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
   d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
-  d.part = wd("part", (size_t)T.nitem * 4 * nl1);
+  d.part = wd("part", (size_t)kSwNSlot * 4 * nl1);
   if (a->memspace == 1) {
     d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   } else {
@@ -312,13 +312,14 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   }
   (void)hipEventRecord(ctx->ev[0][0], s);
   {
-    const dim3 grid((ntile + kSwWgWaves - 1) / kSwWgWaves * T.nitem), wg(64 * kSwWgWaves);
-    hipLaunchKernelGGL(sw_solve_all_kernel<false>, grid, wg, 0, s, d, T, ntile);
-    if (clouds) hipLaunchKernelGGL(sw_solve_all_kernel<true>, grid, wg, 0, s, d, T, ntile);
+    const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
+    const dim3 wg(64 * kSwWgWaves);
+    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, ntile);
+    if (clouds) hipLaunchKernelGGL(sw_solve_all_kernel<true>, dim3(ngrp * T.nitem[1]), wg, 0, s, d, T, ntile);
   }
   (void)hipEventRecord(ctx->ev[0][1], s);
   ctx->ev_valid[0] = true;
-  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T.nitem);
+  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, kSwNSlot);
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -36,12 +36,12 @@ struct SwBandTab {
 };
 
 // Work item of the solve kernel: G (4 or 2) consecutive g-points of one band, carried by one thread per column.
-// Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Item order = g-point order
-// (it is the partial-flux slot); sched[] lists the items heaviest first (launch order).
+// Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Two item sets: set 0 (chunks of
+// 4, then 2) for the clear-sky kernel variant, set 1 (pairs) for the cloudy one, whose per-g-point state is twice
+// as large.  sched[] lists a set's items heaviest first (launch order).  Partial fluxes are always written per
+// PAIR of g-points (slot = first g-point / 2, kSwNSlot slots), so both sets add the 112 g-points in the same order.
 constexpr int kSwMaxItem = 56;
-#ifndef RRTMG_GMAX
-#define RRTMG_GMAX 2
-#endif
+constexpr int kSwNSlot = 56;
 RRTMG_HD int item_band(int it) { return it & 0xff; }
 RRTMG_HD int item_ig0(int it) { return (it >> 8) & 0xff; }
 RRTMG_HD int item_g(int it) { return (it >> 16) & 0xf; }
@@ -50,8 +50,8 @@ RRTMG_HD int item_iw0(int it) { return (it >> 20) & 0xff; }
 struct SwTab {
   const double *t;
   SwBandTab b[kSwNBand];
-  int nitem;
-  int32_t item[kSwMaxItem], sched[kSwMaxItem];
+  int nitem[2];
+  int32_t item[2][kSwMaxItem], sched[2][kSwMaxItem];
   long preflog, tref, exp_tbl;
   long extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3;
   long abari, bbari, cbari, dbari, ebari, fbari, wavenum2;
@@ -86,7 +86,7 @@ struct SwDev {
   uint64_t *mask;      // McICA cloud mask bits [112][nw][col]
   int nw;
   double *scratch;     // [tile][item: first g-point * ...][lay][field][G][64]
-  double *part;        // [item][4][nlay+1][col]  weighted (fu, fd, cu, cd), summed over the item's g-points
+  double *part;        // [slot][4][nlay+1][col]  weighted (fu, fd, cu, cd), summed over the slot's pair of g-points
   int *err;
   // outputs
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
@@ -773,19 +773,20 @@ enum { F_RUP = 0, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
 // optical properties of one layer for one g-point: clear sky and (if requested) total sky
 struct SwLayerOpt { double ref, refd, tra, trad, dbt; };
 
-// Per-item flux sink used by the host emulation, by tests and by the device kernel: the weighted
-// (fu, fd, cu, cd), already summed over the item's g-points, go to part[item][k][level][column].
+// Flux sink of the host emulation, of tests and of the device kernel: the weighted (fu, fd, cu, cd), summed over
+// each PAIR of the item's g-points, go to part[slot][k][level][column].
 struct SwPartSink {
-  double *pfu, *pfd, *pcu, *pcd;
-  long N;
-  RRTMG_HD void emit(int lev, double fu, double fd, double cu, double cd) {
-    pfu[(long)lev * N] = fu; pfd[(long)lev * N] = fd; pcu[(long)lev * N] = cu; pcd[(long)lev * N] = cd;
+  double *pfu, *pfd, *pcu, *pcd;   // slot of the item's first pair
+  long N, slot_stride;             // slot_stride = 4 * (nlay + 1) * ncol
+  RRTMG_HD void emit(int pair, int lev, double fu, double fd, double cu, double cd) {
+    const long o = pair * slot_stride + (long)lev * N;
+    pfu[o] = fu; pfd[o] = fd; pcu[o] = cu; pcd[o] = cd;
   }
 };
 RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int slot, int col) {
   const long N = d.ncol, L1 = d.nlay + 1;
   SwPartSink s;
-  s.N = N;
+  s.N = N; s.slot_stride = 4 * L1 * N;
   s.pfu = d.part + (((long)slot * 4 + 0) * L1) * N + col; s.pfd = d.part + (((long)slot * 4 + 1) * L1) * N + col;
   s.pcu = d.part + (((long)slot * 4 + 2) * L1) * N + col; s.pcd = d.part + (((long)slot * 4 + 3) * L1) * N + col;
   return s;
@@ -972,7 +973,9 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
   for (int g = 0; g < G; ++g) { tdnc[g] = 1.0; rdndc[g] = 0.0; tdbtc[g] = 1.0; tdn[g] = 1.0; rdnd[g] = 0.0; tdbt[g] = 1.0; }
   for (int lev = L; lev >= 0; --lev) {
-    double sfu = 0.0, sfd = 0.0, scu = 0.0, scd = 0.0;
+    double sfu[G / 2], sfd[G / 2], scu[G / 2], scd[G / 2];
+#pragma unroll
+    for (int h = 0; h < G / 2; ++h) { sfu[h] = 0.0; sfd[h] = 0.0; scu[h] = 0.0; scd[h] = 0.0; }
     // (fetching these rows a level ahead costs more in registers than the latency it hides: measured)
     V<G> c_rc, c_rdc, c_r, c_rd;
     if (lev > 0) {
@@ -994,13 +997,11 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
         fu = (tdbt[g] * r + (tdn[g] - tdbt[g]) * rd) * zr;
         fd = tdbt[g] + (tdn[g] - tdbt[g] + tdbt[g] * r * rdnd[g]) * zr;
       }
-      sfu = sfu + zinc[g] * fu; sfd = sfd + zinc[g] * fd; scu = scu + zinc[g] * cu; scd = scd + zinc[g] * cd;
+      const int h = g >> 1;
+      sfu[h] = sfu[h] + zinc[g] * fu; sfd[h] = sfd[h] + zinc[g] * fd; scu[h] = scu[h] + zinc[g] * cu; scd[h] = scd[h] + zinc[g] * cd;
     }
-#ifdef RRTMG_ABL_NOSINK
-    if (sfu == 123.456) sink.emit(lev, sfu, sfd, scu, scd);
-#else
-    sink.emit(lev, sfu, sfd, scu, scd);
-#endif
+#pragma unroll
+    for (int h = 0; h < G / 2; ++h) sink.emit(h, lev, sfu[h], sfd[h], scu[h], scd[h]);
     if (lev > 0) {
       const int l = lev - 1;
       SwLayerOpt oc[G], ot[G];
@@ -1033,10 +1034,10 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 template <int BAND, bool CLD, class Sink>
 RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
   constexpr int ng = SwBandCfg<BAND>::ng;
-  if constexpr (ng >= 4 && RRTMG_GMAX >= 4) {
+  if constexpr (!CLD && ng >= 4) {   // chunks of 4 exist in item set 0 (clear sky) only
     if (g == 4) { sw_solve_thread<BAND, 4, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_GMAX < 4) sw_solve_thread<BAND, 2, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink);
+  if constexpr (CLD || ng % 4 != 0) sw_solve_thread<BAND, 2, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink);
 }
 template <bool CLD, class Sink>
 RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tbl, int item, int col, double *scr, long stride, Sink &sink) {
@@ -1062,7 +1063,7 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
 // one thread per (column, interface level): g-point sum in reference order
-// nparts = number of work items (T.nitem); each partial already holds the sum over its item's g-points
+// nparts = kSwNSlot; each partial already holds the sum over its slot's pair of g-points
 RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev, int nparts) {
   const int L = d.nlay, N = d.ncol;
   double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;

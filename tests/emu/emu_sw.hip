@@ -23,13 +23,16 @@ void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double
 
 static void emu_solve(const SwDev &d, const SwTab &T) {
   std::vector<double> scr((size_t)F_NTOT * d.nlay * 4);
-  for (int slot = 0; slot < T.nitem; ++slot)
-    for (int col = 0; col < d.ncol; ++col) {
-      SwPartSink sink = sw_part_sink(d, slot, col);
-      // the clear-sky variant for cloud-free columns, as the device picks it per tile
-      if (d.anycld[col]) sw_solve_item<true>(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
-      else sw_solve_item<false>(d, T, T.t + T.exp_tbl, T.item[slot], col, scr.data(), 1, sink);
+  for (int col = 0; col < d.ncol; ++col) {
+    // the clear-sky variant (item set 0) for cloud-free columns, as the device picks it per tile
+    const int set = d.anycld[col] ? 1 : 0;
+    for (int i = 0; i < T.nitem[set]; ++i) {
+      const int item = T.item[set][i];
+      SwPartSink sink = sw_part_sink(d, item_iw0(item) >> 1, col);
+      if (set) sw_solve_item<true>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
+      else sw_solve_item<false>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
     }
+  }
 }
 
 extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, double cpdair, const double *consts, char *errbuf, int errlen) {
@@ -71,7 +74,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   if (d.icld >= 1) { d.ctau = wd(nl * kSwNBand); d.cssa = wd(nl * kSwNBand); d.casm = wd(nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   std::vector<uint64_t> mask;
-  d.part = wd((size_t)kSwNGpt * 4 * nl1);
+  d.part = wd((size_t)kSwNSlot * 4 * nl1);
   d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   int errflag = 0;
   d.err = &errflag;
@@ -110,7 +113,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
     }
   }
   emu_solve(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, T.nitem);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, kSwNSlot);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) sw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
