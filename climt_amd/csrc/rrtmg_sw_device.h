@@ -205,29 +205,32 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
   const int layreffr[kSwNBand] = {18, 30, 6, 3, 3, 8, 2, 6, 1, 2, 0, 32, 58, 49};
   const bool upper[kSwNBand] = {true, true, false, false, false, false, false, false, false, false, false, true, true, true};
   auto jp_of = [&](int lay0) { return (int)d.prep[sw_prep_off(L, col, lay0) + P_IDX * 64] & 0xff; };
-  for (int b = 0; b < kSwNBand; ++b) {
-    int fin = 0;
-    if (upper[b]) {
-      int ls = L;
-      for (int lay = laytrop + 1; lay <= L; ++lay) {
-        const int jpm = (lay >= 2) ? jp_of(lay - 2) : 0;
-        const int jpc = jp_of(lay - 1);
-        if (jpm < layreffr[b] && jpc >= layreffr[b]) ls = lay;
-        if (lay == ls) fin = lay;
-      }
-    } else {
-      int ls = laytrop;
-      for (int lay = 1; lay <= laytrop; ++lay) {
-        if (b != 10) {  // band 26 has no layreffr test
-          const int jpc = jp_of(lay - 1);
-          const int jpn = (lay < L) ? jp_of(lay) : 0;
-          if (jpc < layreffr[b] && jpn >= layreffr[b]) ls = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+  // ONE pass over the layers with a sliding (previous, current, next) window of jp; the 14 bands' (ls, fin)
+  // states are updated side by side (same update-and-test order per band as the reference loops)
+  int ls[kSwNBand], fin[kSwNBand];
+#pragma unroll
+  for (int b = 0; b < kSwNBand; ++b) { ls[b] = upper[b] ? L : laytrop; fin[b] = 0; }
+  int jpm = 0, jpc = jp_of(0);
+  for (int lay = 1; lay <= L; ++lay) {
+    const int jpn = (lay < L) ? jp_of(lay) : 0;
+#pragma unroll
+    for (int b = 0; b < kSwNBand; ++b) {
+      if (upper[b]) {
+        if (lay > laytrop) {
+          if (jpm < layreffr[b] && jpc >= layreffr[b]) ls[b] = lay;
+          if (lay == ls[b]) fin[b] = lay;
         }
-        if (lay == ls) fin = lay;
+      } else if (lay <= laytrop) {
+        if (b != 10) {  // band 26 has no layreffr test
+          if (jpc < layreffr[b] && jpn >= layreffr[b]) ls[b] = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+        }
+        if (lay == ls[b]) fin[b] = lay;
       }
     }
-    d.laysolfr[(long)b * N + col] = fin;
+    jpm = jpc; jpc = jpn;
   }
+#pragma unroll
+  for (int b = 0; b < kSwNBand; ++b) d.laysolfr[(long)b * N + col] = fin[b];
 }
 
 // ------------------------------------------------------------------------------------------
