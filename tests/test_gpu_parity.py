@@ -175,6 +175,36 @@ def test_deferred_mode_overlaps_sw_lw_and_reports_errors_at_synchronize(gpu_ctx)
     assert np.array_equal(gpu_ctx.sw_fluxes(c, mcica=True)["swuflx"], hsw["swuflx"])
 
 
+@pytest.mark.parametrize("mcica", [False, True])
+def test_mixed_clear_and_cloudy_tiles_ragged(gpu_ctx, mcica):
+    """300 columns = two cloud-free 64-column tiles, two cloudy ones and a ragged mixed tile: the clear-sky and the
+    cloudy instantiation of the solve kernels both run inside ONE call.  Checked against the host emulation of the
+    same device functions (which the CPU suite pins to the reference Fortran), and: a column's result does not
+    depend (beyond round-off) on which variant its tile got."""
+    from helpers import EmuContext
+    from climt_amd.synthetic import make_columns, overcast
+    N, L = 300, 60
+    c = make_columns(N, L, cloudy=True, seed=21); c.update(BASE); c.update(irng=0, permuteseed=3)
+    if not mcica:
+        c = overcast(c)
+    clear = np.zeros(N, bool); clear[:128] = True; clear[256:280] = True
+    for k in ("cldfr", "cliqwp", "cicewp"):
+        c[k] = np.where(clear[None, :], 0.0, c[k])
+    assert (c["cldfr"][:, 128:256] > 0).any(axis=0).any()
+    emu = EmuContext()
+    sw, lw = gpu_ctx.sw_fluxes(c, mcica=mcica), gpu_ctx.lw_fluxes(c, mcica=mcica)
+    _check(sw, emu.sw_fluxes(c, mcica=mcica))
+    _check(lw, emu.lw_fluxes(c, mcica=mcica))
+    # the clear columns of the mixed tile (cloudy variant) against the same columns in an all-clear call (clear variant)
+    sub = {k: (np.ascontiguousarray(v[..., 256:280]) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    sw2, lw2 = gpu_ctx.sw_fluxes(sub, mcica=mcica), gpu_ctx.lw_fluxes(sub, mcica=mcica)
+    # (the two instantiations are separately compiled -- different FMA contraction -- so "the same" is to round-off)
+    dsw = max(maxdiff(sw[k][:, 256:280], sw2[k]) for k in sw)
+    dlw = max(maxdiff(lw[k][:, 256:280], lw2[k]) for k in lw)
+    print("variant round-off: sw %.3g lw %.3g" % (dsw, dlw))
+    assert dsw <= 1.0e-10 and dlw <= 1.0e-10
+
+
 def test_mcica_mask_matches_reference_generator(gpu_ctx):
     """kissvec / Mersenne-twister sub-column masks are integer work: bit-exact against the committed fixtures'
     generator (the emulated device code was checked against the reference Fortran masks)."""
