@@ -34,6 +34,10 @@ __global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_cloud_column(d, T, col);
 }
+__global__ void __launch_bounds__(64) lw_mr_kernel(LwDev d) {
+  const int col = blockIdx.x * 64 + threadIdx.x;
+  if (col < d.ncol) lw_mr_column(d, col);
+}
 __global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_cloudmc_layer(d, T, col, blockIdx.y);
@@ -54,7 +58,8 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 #define RRTMG_LW_WAVES 2
 #endif
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
-template <bool CLD>
+// MR = true: non-McICA maximum/random overlap (rtrnmr).
+template <bool CLD, bool MR>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile) {
   const int q = blockIdx.x;
   const int tile = q % ntile, k = q / ntile;
@@ -64,7 +69,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_L
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
   LwPartSink sink = lw_part_sink(d, slot, col);
-  lw_solve_item<CLD>(d, T, item, col, scr, 64, sink);
+  lw_solve_item<CLD, MR>(d, T, item, col, scr, 64, sink);
 }
 
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
@@ -121,8 +126,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
   d.fluxfac = (2.0 * asin(1.0)) * 2.e4;       // rrtmg_lw_rad.nomcica.f90:420-421
-  if (!d.mcica && d.icld >= 2)
-    return ctx->fail(RRTMG_ERR_UNSUPPORTED, "non-McICA maximum/maximum-random overlap (rtrnmr) is not built yet; use mcica or icld<=1");
+  const bool maxrand = !d.mcica && d.icld >= 2;   // rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544)
   if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
 
   bool ok = true;
@@ -160,6 +164,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
   d.ncbands = (int32_t *)ctx->buf("lw.w.ncbands", (size_t)N * 4);
   d.tile_cld = (int32_t *)ctx->buf("lw.w.tilecld", (size_t)((N + 63) / 64) * 4);
+  if (maxrand) d.mr = wd("mr", lw_mr_size(N, L));
   if (!d.laytrop || !d.ncbands || !d.tile_cld) ok = false;
   if (clouds) d.ctau = wd("ctau", nl * 16);
   d.nw = (L + 63) / 64;
@@ -192,6 +197,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (clouds) {
     if (!d.mcica) {
       hipLaunchKernelGGL(lw_cloud_kernel, gcol, blk, 0, s, d, T);
+      if (maxrand) hipLaunchKernelGGL(lw_mr_kernel, gcol, blk, 0, s, d);
     } else {
       hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);
       if (a->cldfmcl) {
@@ -215,8 +221,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     }
   }
   (void)hipEventRecord(ctx->ev[1][0], s);
-  hipLaunchKernelGGL(lw_solve_all_kernel<false>, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
-  if (clouds) hipLaunchKernelGGL(lw_solve_all_kernel<true>, dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  if (clouds) {
+    if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+    else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  }
   (void)hipEventRecord(ctx->ev[1][1], s);
   ctx->ev_valid[1] = true;
   hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);

@@ -66,6 +66,7 @@ struct LwDev {
   // clouds
   double *ctau;        // [16][lay][col]  (nomcica: taucloud(lay, ib); mcica: per-band cloudy-sub-column tau)
   int32_t *ncbands;    // [col]
+  double *mr;          // rtrnmr overlap factors [tile][index 0..L+1][MR_N][64] (non-McICA icld >= 2), see lw_mr_column
   int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has cldfr > 0 (selects the solve kernel variant)
   uint64_t *mask;      // [140][nw][col]
   uint64_t *anymask;   // [nw][col]   OR over the sub-columns (icldlyr of rtrnmc)
@@ -376,6 +377,135 @@ RRTMG_HD void lw_anymask_column(const LwDev &d, int col) {
     uint64_t m = 0;
     for (int g = 0; g < kLwNGpt; ++g) m |= d.mask[((long)g * d.nw + w) * d.ncol + col];
     d.anymask[(long)w * d.ncol + col] = m;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Maximum/random overlap factors of rtrnmr for one column (rrtmg_lw_rtrnmr.f90:318-452).  Every array keeps the
+// reference's own index (0 .. nlayers+1): mr[tile][index][field][lane].  The radiative loops read, for layer lev,
+// the upward factors at index lev+1 and the downward ones at index lev-1.  cldfrac(0) and cldfrac(nlayers+1),
+// which the reference reads out of bounds, only ever multiply factors that are zero there; they are taken as 0.
+// ------------------------------------------------------------------------------------------
+enum LwMrField { MR_FACCLD1 = 0, MR_FACCLD2, MR_FACCLR1, MR_FACCLR2, MR_FACCMB1, MR_FACCMB2, MR_ISTCLD,
+                 MR_FACCLD1D, MR_FACCLD2D, MR_FACCLR1D, MR_FACCLR2D, MR_FACCMB1D, MR_FACCMB2D, MR_ISTCLDD, MR_N };
+RRTMG_HD long lw_mr_off(int nlay, int col, int index) {
+  return ((long)(col >> 6) * (nlay + 2) + index) * (MR_N * 64) + (col & 63);
+}
+RRTMG_HD size_t lw_mr_size(int ncol, int nlay) { return (size_t)((ncol + 63) / 64) * (nlay + 2) * MR_N * 64; }
+
+RRTMG_HD void lw_mr_column(const LwDev &d, int col) {
+  const int L = d.nlay, N = d.ncol;
+  auto M = [&](int f, int index) -> double & { return d.mr[lw_mr_off(L, col, index) + f * 64]; };
+  auto cf = [&](int lev) { return (lev >= 1 && lev <= L) ? d.cldfr[(long)(lev - 1) * N + col] : 0.0; };
+  auto cloudy = [&](int lev) { return cf(lev) >= 1.e-6; };
+  for (int i = 0; i <= L + 1; ++i)
+    for (int f = 0; f < MR_N; ++f) M(f, i) = 0.0;
+  double rat1 = 0.0, rat2 = 0.0;
+  M(MR_ISTCLD, 1) = 1.0;
+  M(MR_ISTCLDD, L) = 1.0;
+  for (int lev = 1; lev <= L; ++lev) {
+    if (cloudy(lev)) {
+      M(MR_ISTCLD, lev + 1) = 0.0;
+      if (lev == L) {
+        M(MR_FACCLD1, lev + 1) = 0.0; M(MR_FACCLD2, lev + 1) = 0.0; M(MR_FACCLR1, lev + 1) = 0.0;
+        M(MR_FACCLR2, lev + 1) = 0.0; M(MR_FACCMB1, lev + 1) = 0.0; M(MR_FACCMB2, lev + 1) = 0.0;
+      } else if (cf(lev + 1) >= cf(lev)) {
+        M(MR_FACCLD1, lev + 1) = 0.0; M(MR_FACCLD2, lev + 1) = 0.0;
+        if (M(MR_ISTCLD, lev) == 1.0) {
+          M(MR_FACCLR1, lev + 1) = 0.0; M(MR_FACCLR2, lev + 1) = 0.0;
+          if (cf(lev) < 1.0) M(MR_FACCLR2, lev + 1) = (cf(lev + 1) - cf(lev)) / (1.0 - cf(lev));
+          M(MR_FACCLR2, lev) = 0.0; M(MR_FACCLD2, lev) = 0.0;
+        } else {
+          const double fmax = cf(lev) > cf(lev - 1) ? cf(lev) : cf(lev - 1);
+          if (cf(lev + 1) > fmax) {
+            M(MR_FACCLR1, lev + 1) = rat2;
+            M(MR_FACCLR2, lev + 1) = (cf(lev + 1) - fmax) / (1.0 - fmax);
+          } else if (cf(lev + 1) < fmax) {
+            M(MR_FACCLR1, lev + 1) = (cf(lev + 1) - cf(lev)) / (cf(lev - 1) - cf(lev));
+            M(MR_FACCLR2, lev + 1) = 0.0;
+          } else {
+            M(MR_FACCLR1, lev + 1) = rat2;
+            M(MR_FACCLR2, lev + 1) = 0.0;
+          }
+        }
+        if (M(MR_FACCLR1, lev + 1) > 0.0 || M(MR_FACCLR2, lev + 1) > 0.0) { rat1 = 1.0; rat2 = 0.0; }
+        else { rat1 = 0.0; rat2 = 0.0; }
+      } else {
+        M(MR_FACCLR1, lev + 1) = 0.0; M(MR_FACCLR2, lev + 1) = 0.0;
+        if (M(MR_ISTCLD, lev) == 1.0) {
+          M(MR_FACCLD1, lev + 1) = 0.0;
+          M(MR_FACCLD2, lev + 1) = (cf(lev) - cf(lev + 1)) / cf(lev);
+          M(MR_FACCLR2, lev) = 0.0; M(MR_FACCLD2, lev) = 0.0;
+        } else {
+          const double fmin = cf(lev) < cf(lev - 1) ? cf(lev) : cf(lev - 1);
+          if (cf(lev + 1) <= fmin) {
+            M(MR_FACCLD1, lev + 1) = rat1;
+            M(MR_FACCLD2, lev + 1) = (fmin - cf(lev + 1)) / fmin;
+          } else {
+            M(MR_FACCLD1, lev + 1) = (cf(lev) - cf(lev + 1)) / (cf(lev) - fmin);
+            M(MR_FACCLD2, lev + 1) = 0.0;
+          }
+        }
+        if (M(MR_FACCLD1, lev + 1) > 0.0 || M(MR_FACCLD2, lev + 1) > 0.0) { rat1 = 0.0; rat2 = 1.0; }
+        else { rat1 = 0.0; rat2 = 0.0; }
+      }
+      M(MR_FACCMB1, lev + 1) = M(MR_FACCLR1, lev + 1) * M(MR_FACCLD2, lev) * cf(lev - 1);
+      M(MR_FACCMB2, lev + 1) = M(MR_FACCLD1, lev + 1) * M(MR_FACCLR2, lev) * (1.0 - cf(lev - 1));
+    } else {
+      M(MR_ISTCLD, lev + 1) = 1.0;
+    }
+  }
+  for (int lev = L; lev >= 1; --lev) {
+    if (cloudy(lev)) {
+      M(MR_ISTCLDD, lev - 1) = 0.0;
+      if (lev == 1) {
+        M(MR_FACCLD1D, lev - 1) = 0.0; M(MR_FACCLD2D, lev - 1) = 0.0; M(MR_FACCLR1D, lev - 1) = 0.0;
+        M(MR_FACCLR2D, lev - 1) = 0.0; M(MR_FACCMB1D, lev - 1) = 0.0; M(MR_FACCMB2D, lev - 1) = 0.0;
+      } else if (cf(lev - 1) >= cf(lev)) {
+        M(MR_FACCLD1D, lev - 1) = 0.0; M(MR_FACCLD2D, lev - 1) = 0.0;
+        if (M(MR_ISTCLDD, lev) == 1.0) {
+          M(MR_FACCLR1D, lev - 1) = 0.0; M(MR_FACCLR2D, lev - 1) = 0.0;
+          if (cf(lev) < 1.0) M(MR_FACCLR2D, lev - 1) = (cf(lev - 1) - cf(lev)) / (1.0 - cf(lev));
+          M(MR_FACCLR2D, lev) = 0.0; M(MR_FACCLD2D, lev) = 0.0;
+        } else {
+          const double fmax = cf(lev) > cf(lev + 1) ? cf(lev) : cf(lev + 1);
+          if (cf(lev - 1) > fmax) {
+            M(MR_FACCLR1D, lev - 1) = rat2;
+            M(MR_FACCLR2D, lev - 1) = (cf(lev - 1) - fmax) / (1.0 - fmax);
+          } else if (cf(lev - 1) < fmax) {
+            M(MR_FACCLR1D, lev - 1) = (cf(lev - 1) - cf(lev)) / (cf(lev + 1) - cf(lev));
+            M(MR_FACCLR2D, lev - 1) = 0.0;
+          } else {
+            M(MR_FACCLR1D, lev - 1) = rat2;
+            M(MR_FACCLR2D, lev - 1) = 0.0;
+          }
+        }
+        if (M(MR_FACCLR1D, lev - 1) > 0.0 || M(MR_FACCLR2D, lev - 1) > 0.0) { rat1 = 1.0; rat2 = 0.0; }
+        else { rat1 = 0.0; rat2 = 0.0; }
+      } else {
+        M(MR_FACCLR1D, lev - 1) = 0.0; M(MR_FACCLR2D, lev - 1) = 0.0;
+        if (M(MR_ISTCLDD, lev) == 1.0) {
+          M(MR_FACCLD1D, lev - 1) = 0.0;
+          M(MR_FACCLD2D, lev - 1) = (cf(lev) - cf(lev - 1)) / cf(lev);
+          M(MR_FACCLR2D, lev) = 0.0; M(MR_FACCLD2D, lev) = 0.0;
+        } else {
+          const double fmin = cf(lev) < cf(lev + 1) ? cf(lev) : cf(lev + 1);
+          if (cf(lev - 1) <= fmin) {
+            M(MR_FACCLD1D, lev - 1) = rat1;
+            M(MR_FACCLD2D, lev - 1) = (fmin - cf(lev - 1)) / fmin;
+          } else {
+            M(MR_FACCLD1D, lev - 1) = (cf(lev) - cf(lev - 1)) / (cf(lev) - fmin);
+            M(MR_FACCLD2D, lev - 1) = 0.0;
+          }
+        }
+        if (M(MR_FACCLD1D, lev - 1) > 0.0 || M(MR_FACCLD2D, lev - 1) > 0.0) { rat1 = 0.0; rat2 = 1.0; }
+        else { rat1 = 0.0; rat2 = 0.0; }
+      }
+      M(MR_FACCMB1D, lev - 1) = M(MR_FACCLR1D, lev - 1) * M(MR_FACCLD2D, lev) * cf(lev + 1);
+      M(MR_FACCMB2D, lev - 1) = M(MR_FACCLD1D, lev - 1) * M(MR_FACCLR2D, lev) * (1.0 - cf(lev + 1));
+    } else {
+      M(MR_ISTCLDD, lev - 1) = 1.0;
+    }
   }
 }
 
@@ -781,7 +911,9 @@ RRTMG_HD bool lw_anymask_bit(const LwDev &d, int col, int l) {
 // Radiances leave through `sink` weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543) and summed over
 // the item's g-points in g-point order.
 // CLD = false: the caller guarantees a cloud-free column (the cloud code is compiled out).
-template <int BAND, int G, bool CLD, class Sink>
+// MR = true (non-McICA icld >= 2): rtrnmr, maximum/random overlap of the cloudy layers (rrtmg_lw_rtrnmr.f90:454-700)
+// with the column's overlap factors from lw_mr_column; MR = false: rtrn / rtrnmc.
+template <int BAND, int G, bool CLD, bool MR, class Sink>
 RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, double *scr, long stride, Sink &sink) {
   const int L = d.nlay, N = d.ncol;
   const int ib = BAND - 1;
@@ -814,9 +946,10 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 
   // ---- downward sweep, lev = L .. 1 ---------------------------------------------------------
   double radld[G], radclrd[G], plfrac_bot[G];
+  double cldrad[G], clrrad[G], radmr[G];   // rtrnmr: cloudy / clear parts of the radiance and the overlap carry `rad`
   int iclddn[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; }
+  for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; cldrad[g] = 0.0; clrrad[g] = 0.0; radmr[g] = 0.0; }
   sink.dn(L, 0.0, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
   for (int lev = L; lev >= 1; --lev) {
@@ -858,6 +991,13 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           efcl_band = (1. - exp(-odcld_band)) * cfrac_band;
         }
       }
+    }
+    double mr_start = 0.0, mr_clr1 = 0.0, mr_cld1 = 0.0, mr_cmb1 = 0.0, mr_cmb2 = 0.0, mr_clr2 = 0.0, mr_cld2 = 0.0;
+    if (MR && icldlyr) {
+      mr_start = d.mr[lw_mr_off(L, col, lev) + MR_ISTCLDD * 64];
+      const double *q = d.mr + lw_mr_off(L, col, lev - 1);
+      mr_clr1 = q[MR_FACCLR1D * 64]; mr_cld1 = q[MR_FACCLD1D * 64]; mr_cmb1 = q[MR_FACCMB1D * 64]; mr_cmb2 = q[MR_FACCMB2D * 64];
+      mr_clr2 = q[MR_FACCLR2D * 64]; mr_cld2 = q[MR_FACCLD2D * 64];
     }
     double srd = 0.0, srcd = 0.0;
     V<G> v_atrans, v_bbugas, v_atot, v_bbutot;
@@ -920,7 +1060,21 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbugas = plf * (blay + tfacgas * dplankup);
           bbutot = plf * (blay + tfactot * dplankup);
         }
-        radld[g] = radld[g] - radld[g] * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
+        if constexpr (MR) {
+          if (mr_start == 1.0) { cldrad[g] = cfrac * radld[g]; clrrad[g] = radld[g] - cldrad[g]; radmr[g] = 0.0; }
+          const double ttot = 1.0 - atot;
+          const double cldsrc = bbdtot * atot;
+          cldrad[g] = cldrad[g] * ttot + cfrac * cldsrc;
+          clrrad[g] = clrrad[g] * (1.0 - atrans) + (1.0 - cfrac) * gassrc;
+          radld[g] = cldrad[g] + clrrad[g];
+          const double radmod = radmr[g] * (mr_clr1 * (1. - atrans) + mr_cld1 * ttot) - mr_cmb1 * gassrc + mr_cmb2 * cldsrc;
+          const double oldcld = cldrad[g] - radmod, oldclr = clrrad[g] + radmod;
+          radmr[g] = -radmod + mr_clr2 * oldclr - mr_cld2 * oldcld;
+          cldrad[g] = cldrad[g] + radmr[g];
+          clrrad[g] = clrrad[g] - radmr[g];
+        } else {
+          radld[g] = radld[g] - radld[g] * (atrans + efclfrac * (1. - atrans)) + gassrc + cfrac * (bbdtot * atot - gassrc);
+        }
         v_atot[g] = atot;
         v_bbutot[g] = bbutot;
       } else {
@@ -1011,6 +1165,13 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       }
       V<G> r_atot, r_bbutot;
       if (icldlyr) { r_atot = vload<G>(SP(LF_ATOT, l)); r_bbutot = vload<G>(SP(LF_BBUTOT, l)); }
+      double mr_start = 0.0, mr_clr1 = 0.0, mr_cld1 = 0.0, mr_cmb1 = 0.0, mr_cmb2 = 0.0, mr_clr2 = 0.0, mr_cld2 = 0.0;
+      if (MR && icldlyr) {
+        mr_start = d.mr[lw_mr_off(L, col, lev) + MR_ISTCLD * 64];
+        const double *q = d.mr + lw_mr_off(L, col, lev + 1);
+        mr_clr1 = q[MR_FACCLR1 * 64]; mr_cld1 = q[MR_FACCLD1 * 64]; mr_cmb1 = q[MR_FACCMB1 * 64]; mr_cmb2 = q[MR_FACCMB2 * 64];
+        mr_clr2 = q[MR_FACCLR2 * 64]; mr_cld2 = q[MR_FACCLD2 * 64];
+      }
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
       for (int g = 0; g < G; ++g) {
@@ -1026,7 +1187,21 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         if (icldlyr) {
           const double atot = r_atot[g], bbutot = r_bbutot[g];
           const double gassrc = bbugas * atrans;
-          radlu[g] = radlu[g] - radlu[g] * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
+          if constexpr (MR) {
+            if (mr_start == 1.0) { cldrad[g] = cfrac * radlu[g]; clrrad[g] = radlu[g] - cldrad[g]; radmr[g] = 0.0; }
+            const double ttot = 1.0 - atot;
+            const double cldsrc = bbutot * atot;
+            cldrad[g] = cldrad[g] * ttot + cfrac * cldsrc;
+            clrrad[g] = clrrad[g] * (1.0 - atrans) + (1.0 - cfrac) * gassrc;
+            radlu[g] = cldrad[g] + clrrad[g];
+            const double radmod = radmr[g] * (mr_clr1 * (1.0 - atrans) + mr_cld1 * ttot) - mr_cmb1 * gassrc + mr_cmb2 * cldsrc;
+            const double oldcld = cldrad[g] - radmod, oldclr = clrrad[g] + radmod;
+            radmr[g] = -radmod + mr_clr2 * oldclr - mr_cld2 * oldcld;
+            cldrad[g] = cldrad[g] + radmr[g];
+            clrrad[g] = clrrad[g] - radmr[g];
+          } else {
+            radlu[g] = radlu[g] - radlu[g] * (atrans + efclfrac * (1.0 - atrans)) + gassrc + cfrac * (bbutot * atot - gassrc);
+          }
           if (d.idrv) d_radlu_dt[g] = d_radlu_dt[g] * cfrac * (1.0 - atot) + d_radlu_dt[g] * (1.0 - cfrac) * (1.0 - atrans);
         } else {
           radlu[g] = radlu[g] + (bbugas - radlu[g]) * atrans;
@@ -1047,34 +1222,34 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 }
 
 // Dispatch of one work item (packed, see LwTab) for one column: band switch + G in {4, 2}.
-template <int BAND, bool CLD, class Sink>
+template <int BAND, bool CLD, bool MR, class Sink>
 RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
   constexpr int ng = kLwNg[BAND - 1];
   if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
-    if (g == 4) { lw_solve_thread<BAND, 4, CLD>(d, T, col, ig0, scr, stride, sink); return; }
+    if (g == 4) { lw_solve_thread<BAND, 4, CLD, MR>(d, T, col, ig0, scr, stride, sink); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD>(d, T, col, ig0, scr, stride, sink);
+  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD, MR>(d, T, col, ig0, scr, stride, sink);
 }
-template <bool CLD, class Sink>
+template <bool CLD, bool MR, class Sink>
 RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, double *scr, long stride, Sink &sink) {
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
   switch ((item & 0xff) + 1) {
-    case 1: lw_solve_band<1, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 2: lw_solve_band<2, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 3: lw_solve_band<3, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 4: lw_solve_band<4, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 5: lw_solve_band<5, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 6: lw_solve_band<6, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 7: lw_solve_band<7, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 8: lw_solve_band<8, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 9: lw_solve_band<9, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 10: lw_solve_band<10, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 11: lw_solve_band<11, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 12: lw_solve_band<12, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 13: lw_solve_band<13, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 14: lw_solve_band<14, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 15: lw_solve_band<15, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
-    default: lw_solve_band<16, CLD>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 1: lw_solve_band<1, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 2: lw_solve_band<2, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 3: lw_solve_band<3, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 4: lw_solve_band<4, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 5: lw_solve_band<5, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 6: lw_solve_band<6, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 7: lw_solve_band<7, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 8: lw_solve_band<8, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 9: lw_solve_band<9, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 10: lw_solve_band<10, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 11: lw_solve_band<11, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 12: lw_solve_band<12, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 13: lw_solve_band<13, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 14: lw_solve_band<14, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 15: lw_solve_band<15, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    default: lw_solve_band<16, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
   }
 }
 

@@ -23,8 +23,9 @@ static void emu_lw_solve(const LwDev &d, const LwTab &T) {
       // the clear-sky variant for cloud-free columns, as the device picks it per tile
       bool cld = false;
       if (d.icld >= 1 && d.cldfr) for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(size_t)l * d.ncol + col] > 0.0;
-      if (cld) lw_solve_item<true>(d, T, T.item[slot], col, scr.data(), 1, sink);
-      else lw_solve_item<false>(d, T, T.item[slot], col, scr.data(), 1, sink);
+      if (cld && !d.mcica && d.icld >= 2) lw_solve_item<true, true>(d, T, T.item[slot], col, scr.data(), 1, sink);
+      else if (cld) lw_solve_item<true, false>(d, T, T.item[slot], col, scr.data(), 1, sink);
+      else lw_solve_item<false, false>(d, T, T.item[slot], col, scr.data(), 1, sink);
     }
 }
 
@@ -50,7 +51,6 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
   d.k = k;
   d.fluxfac = (2.0 * asin(1.0)) * 2.e4;
-  if (!d.mcica && d.icld >= 2) return fail(20, "rtrnmr not built");
   d.play = a->play; d.plev = a->plev; d.tlay = a->tlay; d.tlev = a->tlev; d.tsfc = a->tsfc; d.h2o = a->h2ovmr; d.o3 = a->o3vmr;
   d.co2 = a->co2vmr; d.ch4 = a->ch4vmr; d.n2o = a->n2ovmr; d.o2 = a->o2vmr; d.cfc11 = a->cfc11vmr; d.cfc12 = a->cfc12vmr;
   d.cfc22 = a->cfc22vmr; d.ccl4 = a->ccl4vmr; d.emis = a->emis; d.tauaer = a->tauaer;
@@ -74,6 +74,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   if (clouds) {
     if (!d.mcica) {
       for (int c = 0; c < N; ++c) lw_cloud_column(d, T, c);
+      if (d.icld >= 2) { d.mr = wd(lw_mr_size(N, L)); for (int c = 0; c < N; ++c) lw_mr_column(d, c); }
     } else {
       for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_cloudmc_layer(d, T, c, l);
       mask.assign((size_t)kLwNGpt * d.nw * N, 0);

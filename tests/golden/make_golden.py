@@ -104,6 +104,38 @@ def reference_cases():
         print("reference case", name)
 
 
+def lw_maxrand_columns(seed, ncol=40, nlay=60):
+    """Columns for the non-McICA maximum/random overlap (rtrnmr) cases: every cloudy layer has its own fraction,
+    some equal to a neighbour's, some layers overcast (the branches of the overlap-factor recursion)."""
+    from climt_amd.synthetic import make_columns
+    c = make_columns(ncol, nlay, cloudy=True, seed=seed)
+    rng = np.random.default_rng(seed)
+    f = rng.uniform(0.05, 1.0, c["cldfr"].shape)
+    f[:, ::3] = np.round(f[:, ::3] * 4) / 4
+    c["cldfr"] = np.where(c["cldfr"] > 0, np.clip(f, 0.01, 1.0), 0.0)
+    c["cldfr"][:, :8] = np.where(c["cldfr"][:, :8] > 0, 1.0, 0.0)
+    return c
+
+
+def reference_rtrnmr_cases():
+    """ref_lwmr_*.npz: longwave only (the non-McICA shortwave accepts clear/overcast layers only)."""
+    from oracle.ref_driver import RefLW
+    from tools.pack_tables import read_blob
+    from tools.synth_lw_tables import fill_reference_from_blob
+    blob = read_blob(os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin"))
+    lw = RefLW()
+    lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+    for name, seed, idrv, icld in (("maxrand", 31, 0, 2), ("maxrand_idrv", 32, 1, 2), ("maximum", 33, 0, 3)):
+        c = lw_maxrand_columns(seed)
+        c.update(icld=icld, iaer=0, inflg=2, iceflg=1, liqflg=1, idrv=idrv)
+        r = lw.fluxes(c, mcica=False)
+        save = {"flag/seed": np.array(seed), "flag/idrv": np.array(idrv), "flag/icld": np.array(icld), "in/cldfr": c["cldfr"]}
+        for k, v in r.items():
+            save["lw/" + k] = v
+        np.savez_compressed(os.path.join(OUT, "ref_lwmr_%s.npz" % name), **save)
+        print("rtrnmr case", name)
+
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -112,3 +144,4 @@ if __name__ == "__main__":
             r = cache_case(cls, desc)
             print(cls, desc, "->", r)
     reference_cases()
+    reference_rtrnmr_cases()

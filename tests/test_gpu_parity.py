@@ -8,7 +8,7 @@ import os
 import numpy as np
 import pytest
 
-from helpers import REF_CASES, ROOT, load_cache_case, load_ref_case, maxdiff
+from helpers import LWMR_CASES, REF_CASES, ROOT, load_cache_case, load_lwmr_case, load_ref_case, maxdiff
 
 pytestmark = pytest.mark.gpu
 
@@ -36,6 +36,15 @@ def test_lw_vs_reference_fixture_synthetic_tables(gpu_ctx, case):
     if not mcica:
         c["icld"] = 1
     _check(gpu_ctx.lw_fluxes(c, mcica=mcica), exp["lw"])
+
+
+@pytest.mark.parametrize("case", LWMR_CASES)
+def test_lw_rtrnmr_vs_reference_fixture(gpu_ctx, case):
+    """Non-McICA maximum/random (icld 2, 3) overlap: lw_mr_kernel + the MR instantiation of lw_solve_all_kernel."""
+    c, exp = load_lwmr_case(case)
+    out = gpu_ctx.lw_fluxes(c, mcica=False)
+    assert ("duflx_dt" in out) == bool(c["idrv"])
+    _check(out, {k: v for k, v in exp.items() if k in out})
 
 
 def test_native_library_is_what_runs(gpu_ctx):
