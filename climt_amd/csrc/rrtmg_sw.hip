@@ -211,7 +211,12 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   d.inflag = a->inflgsw; d.iceflag = a->iceflgsw; d.liqflag = a->liqflgsw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
   std::string err;
-  rc = sw_scalar_setup(d, a->isolvar, a->adjes, a->dyofyr, a->scon, a->bndsolvar, a->indsolvar, err);
+  std::vector<double> svar_col;
+  {
+    const long omg = ctx->sw_ts.off("sw/sol/mgavgcyc"), osb = ctx->sw_ts.off("sw/sol/sbavgcyc");
+    rc = sw_scalar_setup(d, N, a->isolvar, a->adjes, a->dyofyr, a->scon, a->solcycfrac, a->bndsolvar, a->indsolvar,
+                         omg >= 0 ? ctx->sw_ts.flat.data() + omg : nullptr, osb >= 0 ? ctx->sw_ts.flat.data() + osb : nullptr, svar_col, err);
+  }
   if (rc) return ctx->fail(rc, "%s", err.c_str());
   if (d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "inflgsw=1 has no shortwave implementation in RRTMG_SW (cldprop_sw handles 0 and 2)");
 
@@ -268,6 +273,13 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   const int ntile = (N + 63) / 64;
   d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
   d.part = wd("part", (size_t)kSwNSlot * 4 * nl1);
+  if (!svar_col.empty()) {   // per-column solar-variability multipliers (rare: facular/sunspot amplitudes != 1)
+    double *p = wd("svarcol", svar_col.size());
+    if (!ok) return ctx->status;
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(p, svar_col.data(), svar_col.size() * sizeof(double), hipMemcpyHostToDevice, s));
+    RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));   // svar_col is a local
+    d.svar_col = p;
+  }
   if (a->memspace == 1) {
     d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   } else {

@@ -67,6 +67,7 @@ struct SwDev {
   double adjflux_b[kSwNBand];
   double svar_f, svar_s, svar_i;
   double svar_b[kSwNBand];  // isolvar == 3: per-band multiplier (same for f, s, i)
+  const double *svar_col;   // [3][ncol] per-column (svar_f, svar_s, svar_i) or null (see sw_scalar_setup)
   Constants k;
   // inputs
   const double *play, *plev, *tlay, *h2o, *o3, *co2, *ch4, *n2o, *o2;
@@ -766,6 +767,8 @@ RRTMG_HD double sw_incflux(const SwDev &d, const SwTab &T, int col, int ig, doub
   }
   if (d.isolvar == 3)
     s = d.svar_b[b] * src(B.fac) + d.svar_b[b] * src(B.sns) + d.svar_b[b] * src(B.irr);
+  else if (d.svar_col)
+    s = d.svar_col[col] * src(B.fac) + d.svar_col[(long)d.ncol + col] * src(B.sns) + d.svar_col[2l * d.ncol + col] * src(B.irr);
   else
     s = d.svar_f * src(B.fac) + d.svar_s * src(B.sns) + d.svar_i * src(B.irr);
   return d.adjflux * s * prmu0;

@@ -105,37 +105,90 @@ inline double sw_earth_sun(int idn, double pi) {
   return 1.000110 + .034221 * cos(gamma) + .001289 * sin(gamma) + .000719 * cos(2.0 * gamma) + .000077 * sin(2.0 * gamma);
 }
 
-// Scalar part of inatm_sw: adjflux and the solar-variability multipliers
-// (rrtmg_sw_rad.nomcica.f90:1196-1428).  isolvar == 1 (NRLSSI2 solar-cycle tables) is not built.
-inline int sw_scalar_setup(SwDev &d, int isolvar, double adjes, int dyofyr, double scon, const double *bndsolvar,
-                           const double *indsolvar, std::string &err) {
+// Scalar part of inatm_sw: adjflux and the solar-variability multipliers (rrtmg_sw_rad.nomcica.f90:1196-1428).
+// The reference calls inatm_sw INSIDE its column loop and rescales the facular/sunspot amplitudes `indsolvar`
+// IN PLACE there (:1199-1215): when they differ from 1, column k sees amplitudes that were already pulled k times
+// towards the solar-cycle weight, and the caller's array comes back changed.  That is reproduced: `svar_col`
+// receives per-column (svar_f, svar_s, svar_i) -- [3][ncol] -- whenever the multipliers differ between columns
+// (it stays empty otherwise and the scalars in `d` apply), and `indsolvar` is updated as the reference leaves it.
+// mgavgcyc / sbavgcyc: the 132-entry NRLSSI2 mean-cycle index tables (isolvar = 1).
+inline int sw_scalar_setup(SwDev &d, int ncol, int isolvar, double adjes, int dyofyr, double scon, double solcycfrac,
+                           const double *bndsolvar, double *indsolvar, const double *mgavgcyc, const double *sbavgcyc,
+                           std::vector<double> &svar_col, std::string &err) {
   const double rrsw_scon = (double)1.36822e+03f;   // parrrsw.f90:115 -- a default-real (single precision) literal
   const double Iint = 1360.37, Fint = 0.996047, Sint = -0.511590;
   const double Foffset = 0.14959542, Soffset = 0.00066696, svar_f_avg = 0.1568113, svar_s_avg = 909.21910;
+  const int nsolfrac = 132;
   double solvar[kSwNBand];
   for (int b = 0; b < kSwNBand; ++b) { solvar[b] = 1.0; d.svar_b[b] = 1.0; }
   d.svar_f = d.svar_s = d.svar_i = 1.0;
   d.isolvar = isolvar;
-  if (isolvar < -1 || isolvar > 3 || isolvar == 1) {
-    err = "isolvar=" + std::to_string(isolvar) + " (solar-cycle interpolation) is not supported by this build";
-    return 20;
-  }
-  if (indsolvar && (indsolvar[0] != 1.0 || indsolvar[1] != 1.0)) {
-    // the reference rescales indsolvar IN PLACE once per column (inatm_sw is called inside the column
-    // loop, rrtmg_sw_rad.nomcica.f90:1196-1219), i.e. column-order dependent amplitudes; not reproduced.
-    err = "facular/sunspot amplitude scaling (indsolvar != 1) is not supported by this build";
-    return 20;
-  }
+  svar_col.clear();
+  if (isolvar < -1 || isolvar > 3) { err = "isolvar=" + std::to_string(isolvar) + " is not a solar variability method"; return 20; }
+  if (isolvar == 1 && (!mgavgcyc || !sbavgcyc)) { err = "solar-cycle index tables missing from the shortwave data file"; return 3; }
   double adjflx = adjes;
   if (dyofyr > 0) adjflx = sw_earth_sun(dyofyr, d.k.pi);
-  const double i1 = indsolvar ? indsolvar[0] : 1.0, i2 = indsolvar ? indsolvar[1] : 1.0;
+
+  // interpolated mean-cycle indices (isolvar = 1), the same for every column
+  double svar_f_0 = 0.0, svar_s_0 = 0.0;
+  if (isolvar == 1) {
+    if (solcycfrac <= 0.0) { svar_f_0 = mgavgcyc[0]; svar_s_0 = sbavgcyc[0]; }
+    else if (solcycfrac >= 1.0) { svar_f_0 = mgavgcyc[nsolfrac - 1]; svar_s_0 = sbavgcyc[nsolfrac - 1]; }
+    else {
+      const int sfid = (int)floor(solcycfrac * (nsolfrac - 1)) + 1;
+      const double nsfm1_inv = 1.0 / (nsolfrac - 1);
+      const double fraclo = (sfid - 1) * nsfm1_inv, frachi = sfid * nsfm1_inv;
+      const double intfrac = (solcycfrac - fraclo) / (frachi - fraclo);
+      svar_f_0 = mgavgcyc[sfid - 1] + intfrac * (mgavgcyc[sfid] - mgavgcyc[sfid - 1]);
+      svar_s_0 = sbavgcyc[sfid - 1] + intfrac * (sbavgcyc[sfid] - sbavgcyc[sfid - 1]);
+    }
+  }
+  // per-column multipliers from the amplitudes as column `k` sees them
+  double i1 = indsolvar ? indsolvar[0] : 1.0, i2 = indsolvar ? indsolvar[1] : 1.0;
+  auto multipliers = [&](double a1, double a2, double &f, double &s, double &i) {
+    f = s = i = 1.0;
+    if (scon == 0.0) {
+      if (isolvar == 1) { f = a1 * (svar_f_0 - Foffset) / (svar_f_avg - Foffset); s = a2 * (svar_s_0 - Soffset) / (svar_s_avg - Soffset); i = 1.0; }
+      if (isolvar == 2) { f = (a1 - Foffset) / (svar_f_avg - Foffset); s = (a2 - Soffset) / (svar_s_avg - Soffset); i = 1.0; }
+    } else if (scon > 0.0) {
+      if (isolvar == 0) { const double r = scon / (Fint + Sint + Iint); f = s = i = r; }
+      if (isolvar == 1) {
+        i = (scon - (a1 * Fint + a2 * Sint)) / Iint;
+        f = a1 * (svar_f_0 - Foffset) / (svar_f_avg - Foffset);
+        s = a2 * (svar_s_0 - Soffset) / (svar_s_avg - Soffset);
+      }
+    }
+  };
+  const bool varies = (i1 != 1.0 || i2 != 1.0) && solcycfrac >= 0.0 && solcycfrac <= 1.0;
+  const bool per_column = varies && (isolvar == 1 || (isolvar == 2 && scon == 0.0));
+  if (per_column) svar_col.assign((size_t)3 * ncol, 1.0);
+  for (int k = 0; k < (varies ? ncol : 1); ++k) {
+    if (i1 != 1.0 || i2 != 1.0) {   // rrtmg_sw_rad.nomcica.f90:1199-1215, once per column
+      if (solcycfrac >= 0.0 && solcycfrac < 0.0229) {
+        const double wgt = (solcycfrac + 1.0 - 0.3817) / (1.0229 - 0.3817);
+        i1 = i1 + wgt * (1.0 - i1); i2 = i2 + wgt * (1.0 - i2);
+      }
+      if (solcycfrac >= 0.0229 && solcycfrac <= 0.3817) {
+        const double wgt = (solcycfrac - 0.0229) / (0.3817 - 0.0229);
+        i1 = 1.0 + wgt * (i1 - 1.0); i2 = 1.0 + wgt * (i2 - 1.0);
+      }
+      if (solcycfrac > 0.3817 && solcycfrac <= 1.0) {
+        const double wgt = (solcycfrac - 0.3817) / (1.0229 - 0.3817);
+        i1 = i1 + wgt * (1.0 - i1); i2 = i2 + wgt * (1.0 - i2);
+      }
+    }
+    double f, s, i;
+    multipliers(i1, i2, f, s, i);
+    if (per_column) { svar_col[k] = f; svar_col[(size_t)ncol + k] = s; svar_col[(size_t)2 * ncol + k] = i; }
+    if (k == 0) { d.svar_f = f; d.svar_s = s; d.svar_i = i; }
+  }
+  if (indsolvar) { indsolvar[0] = i1; indsolvar[1] = i2; }
+
   if (scon == 0.0) {
     if (isolvar == -1 && bndsolvar) for (int b = 0; b < kSwNBand; ++b) solvar[b] = bndsolvar[b];
-    if (isolvar == 2) { d.svar_f = (i1 - Foffset) / (svar_f_avg - Foffset); d.svar_s = (i2 - Soffset) / (svar_s_avg - Soffset); d.svar_i = 1.0; }
     if (isolvar == 3) for (int b = 0; b < kSwNBand; ++b) { solvar[b] = bndsolvar ? bndsolvar[b] : 1.0; d.svar_b[b] = solvar[b]; }
   } else if (scon > 0.0) {
     if (isolvar == -1) for (int b = 0; b < kSwNBand; ++b) solvar[b] = bndsolvar ? bndsolvar[b] * scon / rrsw_scon : scon / rrsw_scon;
-    if (isolvar == 0) { const double r = scon / (Fint + Sint + Iint); d.svar_f = d.svar_s = d.svar_i = r; }
     if (isolvar == 3) {
       const double c = Fint + Sint + Iint;
       for (int b = 0; b < kSwNBand; ++b) { solvar[b] = bndsolvar ? bndsolvar[b] * scon / c : scon / c; d.svar_b[b] = solvar[b]; }

@@ -112,7 +112,8 @@ typedef struct rrtmg_sw_args {
   int32_t reserved0;
   double adjes, scon, solcycfrac;
   const double *bndsolvar;   /* [14] (host) or NULL -> ones */
-  const double *indsolvar;   /* [2]  (host) or NULL -> ones */
+  double *indsolvar;         /* [2]  (host) or NULL -> ones; IN/OUT: amplitudes != 1 are rescaled in place once per
+                              * column, as the reference does (rrtmg_sw_rad.nomcica.f90:1199-1215) */
   /* state */
   const double *play, *plev, *tlay, *tlev, *tsfc;
   const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;

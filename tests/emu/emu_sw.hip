@@ -56,7 +56,11 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   if (d.iaer != 0 && d.iaer != 6 && d.iaer != 10) d.iaer = 0;
   d.inflag = a->inflgsw; d.iceflag = a->iceflgsw; d.liqflag = a->liqflgsw; d.mcica = a->mcica ? 1 : 0;
   d.k = k;
-  int rc = sw_scalar_setup(d, a->isolvar, a->adjes, a->dyofyr, a->scon, a->bndsolvar, a->indsolvar, err);
+  std::vector<double> svar_col;
+  const long omg = ts.off("sw/sol/mgavgcyc"), osb = ts.off("sw/sol/sbavgcyc");
+  int rc = sw_scalar_setup(d, a->ncol, a->isolvar, a->adjes, a->dyofyr, a->scon, a->solcycfrac, a->bndsolvar, a->indsolvar,
+                           omg >= 0 ? ts.flat.data() + omg : nullptr, osb >= 0 ? ts.flat.data() + osb : nullptr, svar_col, err);
+  if (!svar_col.empty()) d.svar_col = svar_col.data();
   if (rc) return fail(rc, err);
   d.play = a->play; d.plev = a->plev; d.tlay = a->tlay; d.h2o = a->h2ovmr; d.o3 = a->o3vmr; d.co2 = a->co2vmr;
   d.ch4 = a->ch4vmr; d.n2o = a->n2ovmr; d.o2 = a->o2vmr; d.asdir = a->asdir; d.asdif = a->asdif; d.aldir = a->aldir;

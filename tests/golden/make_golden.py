@@ -136,6 +136,37 @@ def reference_rtrnmr_cases():
         print("rtrnmr case", name)
 
 
+SOLVAR_CASES = [(isolvar, scon, ind, frac)
+                for isolvar in (-1, 0, 1, 2, 3) for scon in (0.0, 1365.0)
+                for ind, frac in (((1.0, 1.0), 0.2), ((1.2, 0.8), 0.01), ((1.2, 0.8), 0.2), ((1.2, 0.8), 0.7))
+                if not (isolvar == 2 and scon > 0)]
+
+
+def solvar_inputs(isolvar, scon, ind, frac):
+    from climt_amd.synthetic import make_columns
+    c = make_columns(12, 30, cloudy=False, seed=5)
+    c.update(icld=0, iaer=0, dyofyr=30, scon=scon, isolvar=isolvar, inflg=0, iceflg=0, liqflg=0, adjes=1.0,
+             solcycfrac=frac, indsolvar=np.array(ind), bndsolvar=np.linspace(0.9, 1.1, 14))
+    if isolvar == 2:   # Mg / SB indices given directly
+        c["indsolvar"] = np.array([0.16 * ind[0], 900.0 * ind[1]])
+    return c
+
+
+def reference_solvar_cases():
+    """ref_sw_solvar.npz: every solar-variability method x internal/given solar constant x facular/sunspot amplitudes
+    (amplitudes != 1 exercise the reference's per-column in-place rescaling) -> total-sky fluxes of 12 clear columns."""
+    from oracle.ref_driver import RefSW
+    sw = RefSW()
+    sw.init()
+    save = {}
+    for i, case in enumerate(SOLVAR_CASES):
+        r = sw.fluxes(solvar_inputs(*case), mcica=False)
+        save["case%02d/swuflx" % i] = r["swuflx"]
+        save["case%02d/swdflx" % i] = r["swdflx"]
+    np.savez_compressed(os.path.join(OUT, "ref_sw_solvar.npz"), **save)
+    print("solvar cases", len(SOLVAR_CASES))
+
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -145,3 +176,4 @@ if __name__ == "__main__":
             print(cls, desc, "->", r)
     reference_cases()
     reference_rtrnmr_cases()
+    reference_solvar_cases()

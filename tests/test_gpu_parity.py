@@ -47,6 +47,18 @@ def test_lw_rtrnmr_vs_reference_fixture(gpu_ctx, case):
     _check(out, {k: v for k, v in exp.items() if k in out})
 
 
+def test_sw_solar_variability_methods_vs_reference_fixture(gpu_ctx):
+    """Every isolvar method (incl. the NRLSSI2 mean solar cycle and the per-column amplitude rescaling quirk)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    from make_golden import SOLVAR_CASES, solvar_inputs
+    z = np.load(os.path.join(ROOT, "tests", "golden", "ref_sw_solvar.npz"))
+    for i, case in enumerate(SOLVAR_CASES):
+        out = gpu_ctx.sw_fluxes(solvar_inputs(*case), mcica=False)
+        for k in ("swuflx", "swdflx"):
+            assert maxdiff(out[k], z["case%02d/%s" % (i, k)]) <= TIGHT, (case, k)
+
+
 def test_native_library_is_what_runs(gpu_ctx):
     """The HIP extension, in-tree, is loaded in this process (no eager/CPU fallback exists)."""
     maps = open("/proc/self/maps").read()

@@ -201,6 +201,13 @@ def pack_sw():
             reduced[k] = (a, dims)      # derived at init by the product
             continue
         blob.add(k, a, dims)
+    # NRLSSI2 mean-solar-cycle index tables (isolvar = 1): array constructors local to inatm_sw
+    src = open(os.path.join(libdir, "rrtmg_sw_rad.nomcica.f90")).read()
+    for name in ("mgavgcyc", "sbavgcyc"):
+        m = re.search(name + r"\(:\)\s*=\s*\(/(.*?)/\)", src, re.S)
+        vals = np.array([float(x) for x in re.findall(r"([0-9]+\.[0-9]+)_rb", m.group(1))])
+        assert vals.size == 132, (name, vals.size)
+        blob.add("sw/sol/" + name, vals, (132,))
     blob.add("sw/meta/synthetic", np.array([0], dtype=np.int32))
     out = os.path.join(ROOT, "climt_amd", "data", "rrtmg_sw_data.bin")
     os.makedirs(os.path.dirname(out), exist_ok=True)
