@@ -64,7 +64,6 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   hipError_t e = hipGetDeviceCount(&n);
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
-  if (const char *env = getenv("RRTMG_HIP_TILE_ORDER")) c->tile_order = atoi(env) != 0;
   *out = c;
   if (e != hipSuccess || n <= 0)
     return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));

@@ -4,6 +4,12 @@
 
 #include <cstdint>
 
+// Build-time experiment switches (never set in the product build; `RRTMG_HIP_BUILD_FLAGS=-D... python climt_amd/build.py`
+// builds a variant library that tools/ab*.sh time next to the product one -- results of RRTMG_ABL_* builds are WRONG
+// by design, they only answer "what does this part cost"): RRTMG_ABL_NOSCRATCH (sweep state to one row),
+// RRTMG_ABL_UNIFORMK (k-table rows collapsed), RRTMG_ABL_UNIFORMLOOKUP / NOTAUG / NOPLANCK (LW), RRTMG_ABL_NORECOMPUTE
+// (SW second-sweep optics); RRTMG_EXACT_DIV (IEEE divide instead of qdiv), RRTMG_SW_NOLDS (transmittance table left
+// in global memory), RRTMG_{SW,LW}_WAVES / RRTMG_SW_WGWAVES / RRTMG_LW_GMAX (occupancy and work-item shape).
 #define RRTMG_HD __host__ __device__ __forceinline__
 #define RRTMG_WAVE 64
 

@@ -45,10 +45,6 @@ struct rrtmg_ctx {
   int *err_dev = nullptr;
   hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [sw|lw][start|stop] around the solve kernel
   bool ev_valid[2] = {false, false};
-  // blockIdx -> (tile, g-group) order of the fused solve launches: 1 = tiles fastest (blocks in flight share a
-  // band: its code stays in the instruction cache and its k-tables in L2), 0 = g-groups fastest.
-  // Speed only; env RRTMG_HIP_TILE_ORDER overrides.
-  int tile_order = 0;
 
   int fail(int code, const char *fmt, ...) {
     char tmp[1024];
