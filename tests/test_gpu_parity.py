@@ -16,11 +16,11 @@ FLUX_TOL, HR_TOL, TIGHT = 1.0e-2, 1.0e-3, 5.0e-9
 BASE = dict(icld=1, iaer=0, adjes=1.0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1)
 
 
-def _check(out, exp):
+def _check(out, exp, tight=TIGHT):
     for k, v in exp.items():
         d = maxdiff(out[k], v)
         assert d <= (HR_TOL if k.endswith(("hr", "hrc")) else FLUX_TOL), (k, d)
-        assert d <= TIGHT, (k, d)
+        assert d <= tight, (k, d)
 
 
 @pytest.mark.parametrize("case", REF_CASES)
@@ -224,6 +224,34 @@ def test_mixed_clear_and_cloudy_tiles_ragged(gpu_ctx, mcica):
     dlw = max(maxdiff(lw[k][:, 256:280], lw2[k]) for k in lw)
     print("variant round-off: sw %.3g lw %.3g" % (dsw, dlw))
     assert dsw <= 1.0e-10 and dlw <= 1.0e-10
+
+
+@pytest.mark.parametrize("ncol,nlay", [(1, 60), (65, 4), (130, 70), (7, 130)])
+def test_edge_shapes_against_emulation(gpu_ctx, ncol, nlay):
+    """One column, ragged tiles, the 4-layer minimum of the kissvec seeding, and > 64 / > 128 layers (two and three
+    cloud-mask words): McICA LW+SW against the host emulation of the device functions."""
+    from helpers import EmuContext
+    from climt_amd.synthetic import make_columns
+    c = make_columns(ncol, nlay, cloudy=True, seed=100 + ncol); c.update(BASE); c.update(irng=0, permuteseed=9, icld=2)
+    if nlay == 4:   # the synthetic cloud band may miss a 4-layer column: put a cloud in
+        c["cldfr"][1:3] = 0.5; c["cliqwp"][1:3] = 40.0; c["cicewp"][1:3] = 0.0
+    emu = EmuContext()
+    # (GPU: fused multiply-adds, host emulation: none -- the round-off gap grows with the layer count)
+    _check(gpu_ctx.sw_fluxes(c, mcica=True), emu.sw_fluxes(c, mcica=True), tight=5.0e-8)
+    _check(gpu_ctx.lw_fluxes(c, mcica=True), emu.lw_fluxes(c, mcica=True), tight=5.0e-8)
+
+
+def test_argument_errors(gpu_ctx):
+    from climt_amd._lib import RRTMGError
+    from climt_amd.synthetic import make_columns
+    c = make_columns(4, 300, seed=1); c.update(BASE)
+    with pytest.raises(RRTMGError):       # more than 256 layers: cloud-mask words
+        gpu_ctx.sw_fluxes(c)
+    c = make_columns(4, 3, cloudy=True, seed=1); c.update(BASE); c.update(irng=0, permuteseed=1)
+    c["cldfr"][:] = 0.5
+    with pytest.raises(RRTMGError):       # kissvec needs four layers of pressure
+        gpu_ctx.lw_fluxes(c, mcica=True)
+    gpu_ctx.lw_fluxes(make_columns(4, 30, seed=2) | BASE)   # the context stays usable
 
 
 def test_mcica_mask_matches_reference_generator(gpu_ctx):
