@@ -108,7 +108,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int tile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;
   if (tile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
-  const int item = T.item[CLD ? 1 : 0][T.sched[CLD ? 1 : 0][k]], slot = item_iw0(item) >> 1;
+  const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
@@ -116,9 +116,9 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   sw_solve_item<CLD>(d, T, sh_exp, item, col, scr, 64, sink);
 }
 
-__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, int nparts) {
+__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, col, blockIdx.y, nparts);
+  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[blockIdx.x] != 0);
 }
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -331,7 +331,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   }
   (void)hipEventRecord(ctx->ev[0][1], s);
   ctx->ev_valid[0] = true;
-  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, kSwNSlot);
+  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -38,8 +38,10 @@ struct SwBandTab {
 // Work item of the solve kernel: G (4 or 2) consecutive g-points of one band, carried by one thread per column.
 // Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Two item sets: set 0 (chunks of
 // 4, then 2) for the clear-sky kernel variant, set 1 (pairs) for the cloudy one, whose per-g-point state is twice
-// as large.  sched[] lists a set's items heaviest first (launch order).  Partial fluxes are always written per
-// PAIR of g-points (slot = first g-point / 2, kSwNSlot slots), so both sets add the 112 g-points in the same order.
+// as large.  sched[] lists a set's items heaviest first (launch order).  Partial fluxes: a cloudy tile writes one
+// slot per PAIR of g-points (slot = first g-point / 2, kSwNSlot slots); a clear tile one slot per CHUNK (= item of
+// set 0), holding (pair0 + pair1).  The flux kernel adds chunk sums, forming (pair0 + pair1) itself for cloudy
+// tiles -- the 112 g-points are added in the same order whichever variant a tile ran.
 constexpr int kSwMaxItem = 56;
 constexpr int kSwNSlot = 56;
 RRTMG_HD int item_band(int it) { return it & 0xff; }
@@ -52,6 +54,7 @@ struct SwTab {
   SwBandTab b[kSwNBand];
   int nitem[2];
   int32_t item[2][kSwMaxItem], sched[2][kSwMaxItem];
+  int32_t chunk_pair0[kSwMaxItem], chunk_npair[kSwMaxItem];   // per chunk (item of set 0): first pair slot, pairs (2 | 1)
   long preflog, tref, exp_tbl;
   long extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3;
   long abari, bbari, cbari, dbari, ebari, fbari, wavenum2;
@@ -1006,8 +1009,14 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
       const int h = g >> 1;
       sfu[h] = sfu[h] + zinc[g] * fu; sfd[h] = sfd[h] + zinc[g] * fd; scu[h] = scu[h] + zinc[g] * cu; scd[h] = scd[h] + zinc[g] * cd;
     }
+    if constexpr (CLD) {
 #pragma unroll
-    for (int h = 0; h < G / 2; ++h) sink.emit(h, lev, sfu[h], sfd[h], scu[h], scd[h]);
+      for (int h = 0; h < G / 2; ++h) sink.emit(h, lev, sfu[h], sfd[h], scu[h], scd[h]);   // one slot per pair
+    } else if constexpr (G == 4) {
+      sink.emit(0, lev, sfu[0] + sfu[1], sfd[0] + sfd[1], scu[0] + scu[1], scd[0] + scd[1]);   // one slot per chunk
+    } else {
+      sink.emit(0, lev, sfu[0], sfd[0], scu[0], scd[0]);
+    }
     if (lev > 0) {
       const int l = lev - 1;
       SwLayerOpt oc[G], ot[G];
@@ -1069,14 +1078,19 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
 // one thread per (column, interface level): g-point sum in reference order
-// nparts = kSwNSlot; each partial already holds the sum over its slot's pair of g-points
-RRTMG_HD void sw_flux_level(const SwDev &d, int col, int lev, int nparts) {
+// pairs = false: the column's tile ran the clear-sky variant, slot c holds chunk c; true: the cloudy variant, one
+// slot per pair of g-points -- the chunk sums are formed here, so the summation order is the same.
+RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool pairs) {
   const int L = d.nlay, N = d.ncol;
   double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
-  const long st = (long)(L + 1) * N;
-  for (int iw = 0; iw < nparts; ++iw) {
-    const double *p = d.part + ((long)iw * 4 * (L + 1) + lev) * N + col;
-    fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
+  const long st = (long)(L + 1) * N, slot = 4 * st;
+  for (int c = 0; c < T.nitem[0]; ++c) {
+    const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * N + col;
+    if (pairs && T.chunk_npair[c] == 2) {
+      fu = fu + (p[0] + p[slot]); fd = fd + (p[st] + p[slot + st]); cu = cu + (p[2 * st] + p[slot + 2 * st]); cd = cd + (p[3 * st] + p[slot + 3 * st]);
+    } else {
+      fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
+    }
   }
   const long o = (long)lev * N + col;
   d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;

@@ -88,6 +88,7 @@ inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
         if (n >= kSwMaxItem) { err = "too many work items"; return false; }
         cost[n] = (nspa[b] == 9 ? 1.0 : 0.6) + g * 1.0;
         T.item[set][n] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);
+        if (set == 0) { T.chunk_pair0[n] = (T.b[b].gs + ig) >> 1; T.chunk_npair[n] = g >> 1; }
         T.sched[set][n] = n;
         ++n;
         ig += g;

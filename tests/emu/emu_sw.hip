@@ -28,7 +28,7 @@ static void emu_solve(const SwDev &d, const SwTab &T) {
     const int set = d.anycld[col] ? 1 : 0;
     for (int i = 0; i < T.nitem[set]; ++i) {
       const int item = T.item[set][i];
-      SwPartSink sink = sw_part_sink(d, item_iw0(item) >> 1, col);
+      SwPartSink sink = sw_part_sink(d, set ? (item_iw0(item) >> 1) : i, col);
       if (set) sw_solve_item<true>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
       else sw_solve_item<false>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
     }
@@ -117,7 +117,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
     }
   }
   emu_solve(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, c, lev, kSwNSlot);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) sw_flux_level(d, T, c, lev, d.anycld[c] != 0);
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) sw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
