@@ -31,6 +31,7 @@ __global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
   if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
 }
 __global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
+  if (!d.tile_cld[blockIdx.x]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_cloud_column(d, T, col);
 }
@@ -39,6 +40,7 @@ __global__ void __launch_bounds__(64) lw_mr_kernel(LwDev d) {
   if (col < d.ncol) lw_mr_column(d, col);
 }
 __global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T) {
+  if (!d.tile_cld[blockIdx.x]) return;
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_cloudmc_layer(d, T, col, blockIdx.y);
 }

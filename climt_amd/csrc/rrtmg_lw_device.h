@@ -328,7 +328,8 @@ RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay)
   for (int ib = 0; ib < 16; ++ib) {
     const double tin = d.taucld ? d.taucld[i * 16 + ib] : 0.0;
     double tau = tin;
-    if (d.inflag == 2 && (cwp >= cldmin || tin >= cldmin)) {
+    // (a sub-column can only be cloudy where cldfrac >= cldmin)
+    if (d.inflag == 2 && d.cldfr[i] >= cldmin && (cwp >= cldmin || tin >= cldmin)) {
       double abscoice = 0.0, abscoliq = 0.0;
       const double radice = d.reice[i];
       if (ciwp == 0.0) {

@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {
 }
 
 __global__ void __launch_bounds__(64) sw_cloud_kernel(SwDev d, SwTab T) {
+  if (!d.tile_cld[blockIdx.x]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
   const int col = blockIdx.x * 64 + threadIdx.x;
   const int lay = blockIdx.y;
   if (col < d.ncol) sw_cloud_layer(d, T, col, lay);

@@ -260,7 +260,8 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
     const long o = ((long)b * L + lay) * N + col;
     double tau = 0.0, ssa = 1.0, asy = 0.0;
     const double tcb = d.taucld ? d.taucld[i * kSwNBand + b] : 0.0;
-    const bool gate = d.mcica ? (cwp >= cldmin || tcb >= cldmin) : (cf >= cldmin && (cwp >= cldmin || tauctot >= cldmin));
+    // (McICA: a sub-column can only be cloudy where cldfrac >= cldmin, mcica_subcol_gen_sw.f90:474-497)
+    const bool gate = cf >= cldmin && (d.mcica ? (cwp >= cldmin || tcb >= cldmin) : (cwp >= cldmin || tauctot >= cldmin));
     if (d.mcica) tau = tcb, ssa = d.ssacld ? d.ssacld[i * kSwNBand + b] : 1.0, asy = d.asmcld ? d.asmcld[i * kSwNBand + b] : 0.0;
     if (gate) {
       if (d.inflag == 0) {
