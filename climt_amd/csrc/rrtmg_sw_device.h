@@ -820,9 +820,10 @@ RRTMG_HD bool sw_mask_bit(const SwDev &d, int iw, int col, int l) {
 // adding-method sweeps need.  The layer state, the species mixture, the interpolation weights and the table
 // rows are evaluated ONCE for the G g-points.  Called in BOTH sweeps: recomputing it is cheaper than spilling
 // five more level arrays per g-point through HBM (profiles/r01_pmc_*.txt).
-template <int BAND, int G, bool CLD>
-RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<G> &c, int col, int l,
-                              SwLayerOpt (&clr)[G], SwLayerOpt (&tot)[G]) {
+// consume(g, clear, total) is called for each g-point right after its optics are ready, so that only ONE g-point's
+// ten layer operators are live at a time (register pressure).
+template <int BAND, int G, bool CLD, class Consume>
+RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<G> &c, int col, int l, Consume &&consume) {
   const int L = d.nlay, N = d.ncol;
   const double *exp_tbl = c.exp_tbl;
   const double prmu0 = c.prmu0, rmu0 = c.rmu0;
@@ -844,6 +845,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
   }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    SwLayerOpt oc, ot;
     // clear-sky optical properties and delta scaling (rrtmg_sw_spcvrt.f90:447-498)
     double ztauc, zomcc, zgcc;
     if (d.tauaer) {
@@ -855,17 +857,17 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
       ztauc = (1.0 - zwf) * ztauc;
       zomcc = qdiv(zomcc - zwf, 1.0 - zwf);
       zgcc = qdiv(zgcc - zf, 1.0 - zf);
-      sw_reftra<false>(exp_tbl, zgcc, prmu0, rmu0, ztauc, zomcc, clr[g].ref, clr[g].refd, clr[g].tra, clr[g].trad);
+      sw_reftra<false>(exp_tbl, zgcc, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad);
     } else {
       // no aerosol: taua = 0, omga = 1, asya = 0 -> zgcc = 0 and the delta scaling is the identity
       ztauc = taur[g] + taug[g];
       zomcc = qdiv(taur[g], ztauc);
       zgcc = 0.0;
-      sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, clr[g].ref, clr[g].refd, clr[g].tra, clr[g].trad);
+      sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad);
     }
-    clr[g].dbt = sw_dbt(exp_tbl, ztauc, rmu0);
-    if (!CLD || !c.cloudy[g]) continue;
-    tot[g] = clr[g];
+    oc.dbt = sw_dbt(exp_tbl, ztauc, rmu0);
+    if (!CLD || !c.cloudy[g]) { consume(g, oc, oc); continue; }
+    ot = oc;
     bool lcld;
     double zc;
     if (d.mcica) { lcld = sw_mask_bit(d, c.iw0 + g, col, l); zc = lcld ? 1.0 : 0.0; }
@@ -881,21 +883,22 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
       sw_reftra<false>(exp_tbl, zgco, prmu0, rmu0, ztauo, zomco, refo, refdo, trao, trado);
       const double dbto = sw_dbt(exp_tbl, ztauo, rmu0);
       if (d.mcica) {
-        tot[g].ref = refo; tot[g].refd = refdo; tot[g].tra = trao; tot[g].trad = trado; tot[g].dbt = dbto;
+        ot.ref = refo; ot.refd = refdo; ot.tra = trao; ot.trad = trado; ot.dbt = dbto;
       } else {
         const double zclear = 1.0 - zc;
-        tot[g].ref = zclear * clr[g].ref + zc * refo; tot[g].refd = zclear * clr[g].refd + zc * refdo;
-        tot[g].tra = zclear * clr[g].tra + zc * trao; tot[g].trad = zclear * clr[g].trad + zc * trado;
-        tot[g].dbt = zclear * clr[g].dbt + zc * dbto;
+        ot.ref = zclear * oc.ref + zc * refo; ot.refd = zclear * oc.refd + zc * refdo;
+        ot.tra = zclear * oc.tra + zc * trao; ot.trad = zclear * oc.trad + zc * trado;
+        ot.dbt = zclear * oc.dbt + zc * dbto;
       }
     } else if (!d.mcica && zc != 0.0) {
       // cloud fraction in (0, 1e-12]: lrtchkcld false -> (0,0,1,1) mixed with weight zcloud
       const double zclear = 1.0 - zc;
       const double dbto = sw_dbt(exp_tbl, ztauc + ptc, rmu0);
-      tot[g].ref = zclear * clr[g].ref; tot[g].refd = zclear * clr[g].refd; tot[g].tra = zclear * clr[g].tra + zc;
-      tot[g].trad = zclear * clr[g].trad + zc;
-      tot[g].dbt = zclear * clr[g].dbt + zc * dbto;
+      ot.ref = zclear * oc.ref; ot.refd = zclear * oc.refd; ot.tra = zclear * oc.tra + zc;
+      ot.trad = zclear * oc.trad + zc;
+      ot.dbt = zclear * oc.dbt + zc * dbto;
     }
+    consume(g, oc, ot);
   }
 }
 
@@ -948,23 +951,20 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
   for (int g = 0; g < G; ++g) { rupc[g] = albp; rupdc[g] = albd; rup[g] = albp; rupd[g] = albd; }
   for (int l = 0; l < L; ++l) {
-    SwLayerOpt oc[G], ot[G];
-    sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, oc, ot);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
+    sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, [&](int g, const SwLayerOpt &oc, const SwLayerOpt &ot) {
       {
-        const double zr = qrcp(1.0 - rupdc[g] * oc[g].refd);
-        const double nrup = oc[g].ref + (oc[g].trad * ((oc[g].tra - oc[g].dbt) * rupdc[g] + oc[g].dbt * rupc[g])) * zr;
-        const double nrupd = oc[g].refd + oc[g].trad * oc[g].trad * rupdc[g] * zr;
+        const double zr = qrcp(1.0 - rupdc[g] * oc.refd);
+        const double nrup = oc.ref + (oc.trad * ((oc.tra - oc.dbt) * rupdc[g] + oc.dbt * rupc[g])) * zr;
+        const double nrupd = oc.refd + oc.trad * oc.trad * rupdc[g] * zr;
         rupc[g] = nrup; rupdc[g] = nrupd;
       }
       if (CLD && c.cloudy[g]) {
-        const double zr = qrcp(1.0 - rupd[g] * ot[g].refd);
-        const double nrup = ot[g].ref + (ot[g].trad * ((ot[g].tra - ot[g].dbt) * rupd[g] + ot[g].dbt * rup[g])) * zr;
-        const double nrupd = ot[g].refd + ot[g].trad * ot[g].trad * rupd[g] * zr;
+        const double zr = qrcp(1.0 - rupd[g] * ot.refd);
+        const double nrup = ot.ref + (ot.trad * ((ot.tra - ot.dbt) * rupd[g] + ot.dbt * rup[g])) * zr;
+        const double nrupd = ot.refd + ot.trad * ot.trad * rupd[g] * zr;
         rup[g] = nrup; rupd[g] = nrupd;
       }
-    }
+    });
     {
       V<G> v0, v1;
 #pragma unroll
@@ -1020,28 +1020,26 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
     }
     if (lev > 0) {
       const int l = lev - 1;
-      SwLayerOpt oc[G], ot[G];
-#ifdef RRTMG_ABL_NORECOMPUTE
-#pragma unroll
-      for (int g = 0; g < G; ++g) { oc[g].ref = 0.1 + 1e-3 * l; oc[g].refd = 0.1; oc[g].tra = 0.8; oc[g].trad = 0.8; oc[g].dbt = 0.7; ot[g] = oc[g]; }
-#else
-      sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, oc, ot);
-#endif
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
+      auto down = [&](int g, const SwLayerOpt &oc, const SwLayerOpt &ot) {
         {
-          const double zr = qrcp(1.0 - oc[g].refd * rdndc[g]);
-          const double ntdn = tdbtc[g] * oc[g].tra + (oc[g].trad * ((tdnc[g] - tdbtc[g]) + tdbtc[g] * oc[g].ref * rdndc[g])) * zr;
-          const double nrdnd = oc[g].refd + oc[g].trad * oc[g].trad * rdndc[g] * zr;
-          tdnc[g] = ntdn; rdndc[g] = nrdnd; tdbtc[g] = oc[g].dbt * tdbtc[g];
+          const double zr = qrcp(1.0 - oc.refd * rdndc[g]);
+          const double ntdn = tdbtc[g] * oc.tra + (oc.trad * ((tdnc[g] - tdbtc[g]) + tdbtc[g] * oc.ref * rdndc[g])) * zr;
+          const double nrdnd = oc.refd + oc.trad * oc.trad * rdndc[g] * zr;
+          tdnc[g] = ntdn; rdndc[g] = nrdnd; tdbtc[g] = oc.dbt * tdbtc[g];
         }
         if (CLD && c.cloudy[g]) {
-          const double zr = qrcp(1.0 - ot[g].refd * rdnd[g]);
-          const double ntdn = tdbt[g] * ot[g].tra + (ot[g].trad * ((tdn[g] - tdbt[g]) + tdbt[g] * ot[g].ref * rdnd[g])) * zr;
-          const double nrdnd = ot[g].refd + ot[g].trad * ot[g].trad * rdnd[g] * zr;
-          tdn[g] = ntdn; rdnd[g] = nrdnd; tdbt[g] = ot[g].dbt * tdbt[g];
+          const double zr = qrcp(1.0 - ot.refd * rdnd[g]);
+          const double ntdn = tdbt[g] * ot.tra + (ot.trad * ((tdn[g] - tdbt[g]) + tdbt[g] * ot.ref * rdnd[g])) * zr;
+          const double nrdnd = ot.refd + ot.trad * ot.trad * rdnd[g] * zr;
+          tdn[g] = ntdn; rdnd[g] = nrdnd; tdbt[g] = ot.dbt * tdbt[g];
         }
-      }
+      };
+#ifdef RRTMG_ABL_NORECOMPUTE
+#pragma unroll
+      for (int g = 0; g < G; ++g) { SwLayerOpt o; o.ref = 0.1 + 1e-3 * l; o.refd = 0.1; o.tra = 0.8; o.trad = 0.8; o.dbt = 0.7; down(g, o, o); }
+#else
+      sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, down);
+#endif
     }
   }
 }
