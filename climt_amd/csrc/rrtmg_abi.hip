@@ -64,6 +64,7 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   hipError_t e = hipGetDeviceCount(&n);
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
+  if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) c->chunk_tiles = v; }
   *out = c;
   if (e != hipSuccess || n <= 0)
     return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));

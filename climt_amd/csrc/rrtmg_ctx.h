@@ -27,6 +27,9 @@ struct rrtmg_ctx {
   hipStream_t stream_lw = nullptr;   // longwave in deferred mode, so SW and LW launches overlap on the GPU
   bool deferred = false;             // rrtmg_hip_set_deferred: device-resident calls return after enqueueing
   bool pending[2] = {false, false};  // [sw|lw] enqueued, status not yet collected
+  // the solve + flux stages run over chunks of at most this many 64-column tiles, so that the sweep-state scratch
+  // and the partial-flux planes stay bounded (~0.23 MB per column and spectrum at 60 layers); env RRTMG_HIP_CHUNK_TILES
+  int chunk_tiles = 512;
   // KISS jump-ahead operators [sw|lw]: host copy, the key they were built for, the device buffer they were uploaded to
   std::vector<uint32_t> kiss_host[2];
   int kiss_key[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};

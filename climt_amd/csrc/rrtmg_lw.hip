@@ -62,20 +62,20 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
 // MR = true: non-McICA maximum/random overlap (rtrnmr).
 template <bool CLD, bool MR>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int ntile) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int q = blockIdx.x;
-  const int tile = q % ntile, k = q / ntile;
+  const int ctile = q % ntile, tile = tile0 + ctile, k = q / ntile;
   if ((d.tile_cld[tile] != 0) != CLD) return;
   const int slot = T.sched[k], item = T.item[slot];
   const int col = tile * 64 + threadIdx.x;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)tile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
+  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
   LwPartSink sink = lw_part_sink(d, slot, col);
   lw_solve_item<CLD, MR>(d, T, item, col, scr, 64, sink);
 }
 
-__global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T, int tile0) {
+  const int col = (tile0 + blockIdx.x) * 64 + threadIdx.x;
   if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem);
 }
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
@@ -177,8 +177,9 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   }
   const int ntile = (N + 63) / 64;
   const int nk = d.idrv ? 6 : 4;
-  d.scratch = wd("scratch", (size_t)ntile * kLwNGpt * LF_N * L * 64);
-  d.part = wd("part", (size_t)T.nitem * nk * nl1);
+  const int ctile = ntile < ctx->chunk_tiles ? ntile : ctx->chunk_tiles;   // tiles per solve chunk
+  d.scratch = wd("scratch", (size_t)ctile * kLwNGpt * LF_N * L * 64);
+  d.part = wd("part", (size_t)T.nitem * nk * (L + 1) * ctile * 64);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
   if (a->memspace == 1) {
@@ -222,15 +223,20 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
     }
   }
-  (void)hipEventRecord(ctx->ev[1][0], s);
-  hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
-  if (clouds) {
-    if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
-    else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(ntile * T.nitem), blk, 0, s, d, T, ntile);
+  // solve + band integration, one column chunk at a time (see sw_fluxes_impl)
+  for (int t0 = 0; t0 < ntile; t0 += ctile) {
+    const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
+    d.col0 = t0 * 64; d.pcols = ctile * 64;
+    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][0], s);
+    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
+    if (clouds) {
+      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
+      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
+    }
+    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][1], s);
+    hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
   }
-  (void)hipEventRecord(ctx->ev[1][1], s);
   ctx->ev_valid[1] = true;
-  hipLaunchKernelGGL(lw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
   hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

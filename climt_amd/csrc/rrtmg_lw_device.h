@@ -72,7 +72,8 @@ struct LwDev {
   uint64_t *anymask;   // [nw][col]   OR over the sub-columns (icldlyr of rtrnmc)
   int nw;
   double *scratch;
-  double *part;        // [item][nk][nlay+1][col], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd summed over the item
+  double *part;        // [item][nk][nlay+1][pcols], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd summed over the item
+  int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
   int *err;
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
 };
@@ -889,8 +890,8 @@ struct LwPartSink {
 RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   LwPartSink s;
   const int nk = d.idrv ? 6 : 4;
-  s.N = d.ncol; s.st = (long)(d.nlay + 1) * d.ncol; s.idrv = d.idrv != 0;
-  s.p = d.part + ((long)slot * nk * (d.nlay + 1)) * d.ncol + col;
+  s.N = d.pcols; s.st = (long)(d.nlay + 1) * d.pcols; s.idrv = d.idrv != 0;
+  s.p = d.part + ((long)slot * nk * (d.nlay + 1)) * d.pcols + (col - d.col0);
   return s;
 }
 
@@ -1262,10 +1263,10 @@ RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, in
   (void)T;
   const int L = d.nlay, N = d.ncol;
   const int nk = d.idrv ? 6 : 4;
-  const long st = (long)(L + 1) * N;
+  const long st = (long)(L + 1) * d.pcols;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
   for (int iw = 0; iw < nparts; ++iw) {
-    const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * N + col;
+    const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * d.pcols + (col - d.col0);
     t0 = t0 + p[0]; t1 = t1 + p[st]; t2 = t2 + p[2 * st]; t3 = t3 + p[3 * st];
     if (d.idrv) { t4 = t4 + p[4 * st]; t5 = t5 + p[5 * st]; }
   }

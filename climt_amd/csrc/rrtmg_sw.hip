@@ -87,7 +87,7 @@ constexpr int kExpTblN = 10001;
 // out (no spills, more resident wavefronts), CLD = true the tiles flagged by sw_prep_kernel; a wavefront whose
 // tile belongs to the other variant exits at once.
 template <bool CLD>
-__global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int ntile) {
+__global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x;
   {
@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
     bool mine = false;
     for (int w = 0; w < kSwWgWaves; ++w) {
       const int t = (q % ngrp) * kSwWgWaves + w;
-      if (t < ntile && (d.tile_cld[t] != 0) == CLD) mine = true;
+      if (t < ntile && (d.tile_cld[tile0 + t] != 0) == CLD) mine = true;
     }
     if (!mine) return;
   }
@@ -107,19 +107,20 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   __syncthreads();
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int tile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;
-  if (tile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
+  const int ctile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;   // tile within the chunk
+  const int tile = tile0 + ctile;
+  if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)tile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<CLD>(d, T, sh_exp, item, col, scr, 64, sink);
 }
 
-__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[blockIdx.x] != 0);
+__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T, int tile0) {
+  const int tile = tile0 + blockIdx.x, col = tile * 64 + threadIdx.x;
+  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[tile] != 0);
 }
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -272,8 +273,9 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
-  d.scratch = wd("scratch", (size_t)ntile * kSwNGpt * F_NTOT * L * 64);
-  d.part = wd("part", (size_t)kSwNSlot * 4 * nl1);
+  const int ctile = ntile < ctx->chunk_tiles ? ntile : ctx->chunk_tiles;   // tiles per solve chunk
+  d.scratch = wd("scratch", (size_t)ctile * kSwNGpt * F_NTOT * L * 64);
+  d.part = wd("part", (size_t)kSwNSlot * 4 * (L + 1) * ctile * 64);
   if (!svar_col.empty()) {   // per-column solar-variability multipliers (rare: facular/sunspot amplitudes != 1)
     double *p = wd("svarcol", svar_col.size());
     if (!ok) return ctx->status;
@@ -323,16 +325,20 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       }
     }
   }
-  (void)hipEventRecord(ctx->ev[0][0], s);
-  {
-    const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
+  // solve + spectral integration, one column chunk at a time (the events bracket the solve launches of the LAST chunk;
+  // with a single chunk -- up to chunk_tiles * 64 columns -- that is the whole solve)
+  for (int t0 = 0; t0 < ntile; t0 += ctile) {
+    const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
+    d.col0 = t0 * 64; d.pcols = ctile * 64;
+    const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
-    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, ntile);
-    if (clouds) hipLaunchKernelGGL(sw_solve_all_kernel<true>, dim3(ngrp * T.nitem[1]), wg, 0, s, d, T, ntile);
+    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[0][0], s);
+    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, t0, nt);
+    if (clouds) hipLaunchKernelGGL(sw_solve_all_kernel<true>, dim3(ngrp * T.nitem[1]), wg, 0, s, d, T, t0, nt);
+    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[0][1], s);
+    hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
   }
-  (void)hipEventRecord(ctx->ev[0][1], s);
   ctx->ev_valid[0] = true;
-  hipLaunchKernelGGL(sw_flux_kernel, dim3(ntile, L + 1), blk, 0, s, d, T);
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

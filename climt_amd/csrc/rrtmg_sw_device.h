@@ -90,7 +90,8 @@ struct SwDev {
   uint64_t *mask;      // McICA cloud mask bits [112][nw][col]
   int nw;
   double *scratch;     // [tile][item: first g-point * ...][lay][field][G][64]
-  double *part;        // [slot][4][nlay+1][col]  weighted (fu, fd, cu, cd), summed over the slot's pair of g-points
+  double *part;        // [slot][4][nlay+1][pcols]  weighted (fu, fd, cu, cd) of the columns col0 .. col0+pcols-1
+  int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
   int *err;
   // outputs
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
@@ -794,7 +795,8 @@ struct SwPartSink {
   }
 };
 RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int slot, int col) {
-  const long N = d.ncol, L1 = d.nlay + 1;
+  const long N = d.pcols, L1 = d.nlay + 1;
+  col -= d.col0;
   SwPartSink s;
   s.N = N; s.slot_stride = 4 * L1 * N;
   s.pfu = d.part + (((long)slot * 4 + 0) * L1) * N + col; s.pfd = d.part + (((long)slot * 4 + 1) * L1) * N + col;
@@ -1080,11 +1082,11 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // pairs = false: the column's tile ran the clear-sky variant, slot c holds chunk c; true: the cloudy variant, one
 // slot per pair of g-points -- the chunk sums are formed here, so the summation order is the same.
 RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool pairs) {
-  const int L = d.nlay, N = d.ncol;
+  const int L = d.nlay, N = d.ncol, P = d.pcols;
   double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
-  const long st = (long)(L + 1) * N, slot = 4 * st;
+  const long st = (long)(L + 1) * P, slot = 4 * st;
   for (int c = 0; c < T.nitem[0]; ++c) {
-    const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * N + col;
+    const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
     if (pairs && T.chunk_npair[c] == 2) {
       fu = fu + (p[0] + p[slot]); fd = fd + (p[st] + p[slot + st]); cu = cu + (p[2 * st] + p[slot + 2 * st]); cd = cd + (p[3 * st] + p[slot + 3 * st]);
     } else {

@@ -65,6 +65,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   d.nw = (L + 63) / 64;
   std::vector<uint64_t> mask, anym;
   const int nk = d.idrv ? 6 : 4;
+  d.col0 = 0; d.pcols = N;
   d.part = wd((size_t)kLwNGpt * nk * nl1);
   d.uflx = a->uflx; d.dflx = a->dflx; d.hr = a->hr; d.uflxc = a->uflxc; d.dflxc = a->dflxc; d.hrc = a->hrc;
   d.duflx_dt = a->duflx_dt; d.duflxc_dt = a->duflxc_dt;

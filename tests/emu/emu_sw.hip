@@ -78,6 +78,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
   if (d.icld >= 1) { d.ctau = wd(nl * kSwNBand); d.cssa = wd(nl * kSwNBand); d.casm = wd(nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   std::vector<uint64_t> mask;
+  d.col0 = 0; d.pcols = N;
   d.part = wd((size_t)kSwNSlot * 4 * nl1);
   d.swuflx = a->swuflx; d.swdflx = a->swdflx; d.swhr = a->swhr; d.swuflxc = a->swuflxc; d.swdflxc = a->swdflxc; d.swhrc = a->swhrc;
   int errflag = 0;

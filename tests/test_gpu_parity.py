@@ -254,6 +254,22 @@ def test_argument_errors(gpu_ctx):
     gpu_ctx.lw_fluxes(make_columns(4, 30, seed=2) | BASE)   # the context stays usable
 
 
+def test_column_chunks_are_invisible(gpu_ctx, monkeypatch):
+    """The solve + spectral-integration stages run over chunks of at most RRTMG_HIP_CHUNK_TILES 64-column tiles (bounded
+    scratch): 5 ragged chunks give bitwise the results of one."""
+    from climt_amd._lib import Context
+    from climt_amd.synthetic import make_columns
+    from helpers import CONSTANTS, CPDAIR
+    c = make_columns(600, 40, cloudy=True, seed=77); c.update(BASE); c.update(irng=0, permuteseed=5)
+    c["cldfr"][:, 128:320] = 0.0; c["cliqwp"][:, 128:320] = 0.0; c["cicewp"][:, 128:320] = 0.0   # some clear tiles
+    ref_sw, ref_lw = gpu_ctx.sw_fluxes(c, mcica=True), gpu_ctx.lw_fluxes(c, mcica=True)
+    monkeypatch.setenv("RRTMG_HIP_CHUNK_TILES", "2")
+    small = Context(0); small.set_constants(**CONSTANTS); small.sw_init(CPDAIR); small.lw_init(CPDAIR)
+    sw, lw = small.sw_fluxes(c, mcica=True), small.lw_fluxes(c, mcica=True)
+    assert all(np.array_equal(sw[k], ref_sw[k]) for k in sw)
+    assert all(np.array_equal(lw[k], ref_lw[k]) for k in lw)
+
+
 def test_mcica_mask_matches_reference_generator(gpu_ctx):
     """kissvec / Mersenne-twister sub-column masks are integer work: bit-exact against the committed fixtures'
     generator (the emulated device code was checked against the reference Fortran masks)."""
