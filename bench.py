@@ -100,11 +100,13 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL output all-gather (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 logic)")
+    ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (with --dist-backend gloo)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus and world > 1:
         a.gpus = world
     dist = None
@@ -112,7 +114,10 @@ def main():
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if a.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(a.dist_backend, rank=rank, world_size=world)
 
     from climt_amd import _hip
     from climt_amd._lib import LW_OUT, SW_OUT, Context
@@ -133,34 +138,55 @@ def main():
     # outputs: one flat device buffer holding the 12 arrays (so that one all-gather moves them all)
     sizes = [(k, (L + lev) * N) for k, lev in SW_OUT] + [(k, (L + lev) * N) for k, lev in LW_OUT]
     total = sum(s for _, s in sizes)
+    # Two output buffers (N>1): the RCCL all-gather of step i runs while step i+1 computes into the other one.
+    nbuf = 2 if world > 1 else 1
     if world > 1:
         import torch
-        flat = torch.empty(total, dtype=torch.float64, device="cuda:%d" % local)
-        gathered = torch.empty(total * world, dtype=torch.float64, device="cuda:%d" % local)
-        base = flat.data_ptr()
+        flats = [torch.empty(total, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
+        gathered = [torch.empty(total * world, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
+        bases = [f.data_ptr() for f in flats]
     else:
-        flat = _hip.DeviceArray((total,))
-        base = flat.ptr
-    off, sw_out, lw_out = 0, {}, {}
-    for i, (k, s) in enumerate(sizes):
-        (sw_out if i < 6 else lw_out)[k] = base + 8 * off
-        off += s
+        flats = [_hip.DeviceArray((total,))]
+        bases = [flats[0].ptr]
+    outs = []
+    for base in bases:
+        off, so, lo = 0, {}, {}
+        for i, (k, s) in enumerate(sizes):
+            (so if i < 6 else lo)[k] = base + 8 * off
+            off += s
+        outs.append((so, lo))
+    sw_out, lw_out = outs[0]
 
     # one step = LW+SW of the whole batch, outputs complete (and checked) when it returns.  By default the two
     # spectra are enqueued in deferred mode on two streams so that they overlap on the GPU.
     ctx.set_deferred(not a.serial)
 
+    state = {"i": 0, "work": None}
+
+    def drain():
+        """Wait (host side) for the all-gather in flight, if any: its source buffer may be reused afterwards."""
+        if state["work"] is not None:
+            import torch
+            state["work"].wait()
+            torch.cuda.synchronize()
+            state["work"] = None
+
     def step():
-        ctx.sw_fluxes(inp, mcica=a.cloudy, out=sw_out, memspace=1)
-        ctx.lw_fluxes(inp, mcica=a.cloudy, out=lw_out, memspace=1)
-        ctx.synchronize()
+        b = state["i"] % nbuf
+        state["i"] += 1
+        so, lo = outs[b]
+        ctx.sw_fluxes(inp, mcica=a.cloudy, out=so, memspace=1)
+        ctx.lw_fluxes(inp, mcica=a.cloudy, out=lo, memspace=1)
+        ctx.synchronize()          # this step's outputs are complete and checked; the previous gather ran meanwhile
         if world > 1 and not a.no_gather:
-            dist.all_gather_into_tensor(gathered, flat)
+            drain()
+            state["work"] = dist.all_gather_into_tensor(gathered[b], flats[b], async_op=True)
 
     def fence():
         ctx.synchronize()
         if world > 1:
             import torch
+            drain()
             dist.barrier()
             torch.cuda.synchronize()
         else:
@@ -214,7 +240,7 @@ def main():
             "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "rrtmg_lw+sw_%s_%dcol_x_%dlev_per_gpu" % ("mcica_cloudy" if a.cloudy else "clear_sky", N, L),
-                       "columns_per_gpu": N, "levels": L, "parallelism": "columns sharded x%d%s" % (world, "" if world == 1 or a.no_gather else " + RCCL all-gather of outputs"),
+                       "columns_per_gpu": N, "levels": L, "parallelism": "columns sharded x%d%s" % (world, "" if world == 1 or a.no_gather else " + RCCL all-gather of outputs (double-buffered: overlaps the next step's compute)"),
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
                        "lw_k_tables": "synthetic (reference LW data file missing)", "sw_k_tables": "reference"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
