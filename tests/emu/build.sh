@@ -1,11 +1,17 @@
 #!/usr/bin/env bash
-# TEST INFRASTRUCTURE ONLY: builds tests/_emu/librrtmg_emu.so (host emulation of the device functions)
+# TEST INFRASTRUCTURE ONLY: builds tests/_emu/librrtmg_emu.so (host emulation of the device functions).
+# The two emulation units are compiled concurrently, then linked.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
-mkdir -p "$ROOT/tests/_emu"
-SRC="$HERE/emu_sw.hip"
-[ -f "$HERE/emu_lw.hip" ] && SRC="$SRC $HERE/emu_lw.hip"
-hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -shared -ffp-contract=off -o "$ROOT/tests/_emu/librrtmg_emu.so" \
-  $SRC "$ROOT/climt_amd/csrc/rrtmg_tables.cpp" "$ROOT/climt_amd/csrc/rrtmg_mt.cpp"
+OUT="$ROOT/tests/_emu"
+mkdir -p "$OUT"
+CC="hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -ffp-contract=off"
+pids=()
+for src in "$HERE/emu_sw.hip" "$HERE/emu_lw.hip" "$ROOT/climt_amd/csrc/rrtmg_tables.cpp" "$ROOT/climt_amd/csrc/rrtmg_mt.cpp"; do
+  $CC -c "$src" -o "$OUT/$(basename "$src").o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+$CC -shared -o "$OUT/librrtmg_emu.so" "$OUT"/*.o
 echo "built tests/_emu/librrtmg_emu.so"
