@@ -187,6 +187,7 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
   const double amd = 28.9660, amw = 18.0160;
   int laytrop = 0;
   double amttl = 0.0, wvttl = 0.0;
+#pragma unroll 8   // independent loads: keep several layers in flight
   for (int l = 0; l < L; ++l) {
     const double *q = d.prep + lw_prep_off(L, col, l);
     laytrop += ((int)q[LP_IDX * 64] >> 30) & 1;

@@ -194,6 +194,7 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
   (void)T;
   const int L = d.nlay, N = d.ncol;
   int laytrop = 0, anycld = 0;
+#pragma unroll 8   // independent loads: keep several layers in flight
   for (int l = 0; l < L; ++l) {
     laytrop += ((int)d.prep[sw_prep_off(L, col, l) + P_IDX * 64] >> 28) & 1;
     if (d.icld >= 1 && d.cldfr && d.cldfr[(long)l * N + col] > 0.0) anycld = 1;
@@ -216,6 +217,7 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
 #pragma unroll
   for (int b = 0; b < kSwNBand; ++b) { ls[b] = upper[b] ? L : laytrop; fin[b] = 0; }
   int jpm = 0, jpc = jp_of(0);
+#pragma unroll 8
   for (int lay = 1; lay <= L; ++lay) {
     const int jpn = (lay < L) ? jp_of(lay) : 0;
 #pragma unroll
