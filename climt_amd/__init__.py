@@ -1,6 +1,8 @@
 """climt_amd -- MI355X-native RRTMG longwave + shortwave radiation, drop-in for
-climt.RRTMGLongwave / climt.RRTMGShortwave (climt/_components/rrtmg/__init__.py:1-4)."""
+climt.RRTMGLongwave / climt.RRTMGShortwave (climt/_components/rrtmg/__init__.py:1-4), plus the zenith-angle producer
+upstream of the shortwave, climt.Instellation."""
 from ._lib import Context, RRTMGError  # noqa: F401
+from .instellation import Instellation  # noqa: F401
 from .rrtmg import RRTMGLongwave, RRTMGShortwave  # noqa: F401
 
-__all__ = ["RRTMGLongwave", "RRTMGShortwave", "Context", "RRTMGError"]
+__all__ = ["RRTMGLongwave", "RRTMGShortwave", "Instellation", "Context", "RRTMGError"]

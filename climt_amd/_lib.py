@@ -69,6 +69,7 @@ def load_library():
     lib.rrtmg_hip_lw_tables_synthetic.argtypes = [_vp]
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
     lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
+    lib.rrtmg_hip_zenith_angle.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
@@ -149,6 +150,17 @@ class Context:
     def synchronize(self):
         """Wait for all enqueued work; in deferred mode this is where device-side errors are raised."""
         self._ck(self.lib.rrtmg_hip_synchronize(self.h))
+
+    def zenith_angle(self, lat_deg, lon_deg, julian_centuries, out=None, memspace=0, ncol=None):
+        """Zenith angle (radians) of every column; host arrays, or device pointers with memspace=1 (then `ncol`)."""
+        if memspace:
+            self._ck(self.lib.rrtmg_hip_zenith_angle(self.h, int(ncol), 1, int(lat_deg), int(lon_deg), float(julian_centuries), int(out)))
+            return out
+        lat = np.ascontiguousarray(lat_deg, dtype=np.float64)
+        lon = np.ascontiguousarray(lon_deg, dtype=np.float64)
+        z = np.empty(lat.shape) if out is None else out
+        self._ck(self.lib.rrtmg_hip_zenith_angle(self.h, lat.size, 0, lat.ctypes.data, lon.ctypes.data, float(julian_centuries), z.ctypes.data))
+        return z
 
     def set_deferred(self, on=True):
         """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams."""

@@ -12,7 +12,7 @@ outputs (last bullet).
 import numpy as np
 
 try:  # pragma: no cover - sympl is absent in the build container
-    from sympl import DataArray, TendencyComponent, get_constant, initialize_numpy_arrays_with_properties  # noqa: F401
+    from sympl import DataArray, DiagnosticComponent, TendencyComponent, get_constant, initialize_numpy_arrays_with_properties  # noqa: F401
     HAVE_SYMPL = True
 except ImportError:
     HAVE_SYMPL = False
@@ -72,7 +72,9 @@ except ImportError:
     }
     _TO_BASE = {"hPa": ("Pa", 100.0), "Pa": ("Pa", 1.0), "kPa": ("Pa", 1000.0), "kg m^-2": ("kg m^-2", 1.0), "g m^-2": ("kg m^-2", 1.e-3),
                 "K day^-1": ("K s^-1", 1.0 / 86400.0), "K s^-1": ("K s^-1", 1.0), "degK s^-1": ("K s^-1", 1.0),
-                "degrees": ("radians", np.pi / 180.0), "radians": ("radians", 1.0), "m": ("m", 1.0), "um": ("m", 1.e-6)}
+                "degrees": ("radians", np.pi / 180.0), "radians": ("radians", 1.0),
+                "degrees_north": ("degrees_north", 1.0), "degrees_N": ("degrees_north", 1.0),
+                "degrees_east": ("degrees_east", 1.0), "degrees_E": ("degrees_east", 1.0), "m": ("m", 1.0), "um": ("m", 1.e-6)}
 
     def _canon(u):
         u = (u or "").strip()
@@ -174,3 +176,10 @@ except ImportError:
             raw = self._extract(state)
             tendencies, diagnostics = self.array_call(raw)
             return self._wrap(tendencies, self.tendency_properties), self._wrap(diagnostics, self.diagnostic_properties)
+
+    class DiagnosticComponent(TendencyComponent):
+        """sympl.DiagnosticComponent stand-in: array_call(raw) -> diagnostics only."""
+
+        def __call__(self, state):
+            raw = self._extract(state)
+            return self._wrap(self.array_call(raw), self.diagnostic_properties)

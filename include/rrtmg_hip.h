@@ -99,6 +99,13 @@ int rrtmg_hip_lw_tables_synthetic(const rrtmg_ctx *ctx);
 /* read back a reduced table built at init (for tests): name e.g. "sw/kg16/absa"; returns element count, or <0 */
 long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long capacity);
 
+/* ---- upstream of the shortwave: zenith angle (climt Instellation) ----------------------------- */
+/* zenith[i] (radians, clamped to pi/2 on the night side) of column i at `julian_centuries` (days since
+ * 2000-01-01 12:00 / 36525): replaces climt/_components/instellation/component.py:85-135 (_instellation_kernel_np; sun
+ * position helpers :138-191 are evaluated on the host).  lat/lon in degrees; memspace as in the flux calls. */
+int rrtmg_hip_zenith_angle(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat_deg, const double *lon_deg,
+                           double julian_centuries, double *zenith);
+
 /* ---- shortwave ------------------------------------------------------------------------ */
 typedef struct rrtmg_sw_args {
   int32_t ncol, nlay;

@@ -167,6 +167,15 @@ def reference_solvar_cases():
     print("solvar cases", len(SOLVAR_CASES))
 
 
+def instellation_cases():
+    """climt_cache_TestInstellation-{column,3d}.npz: the expected zenith angles of the reference's own golden caches
+    (inputs are climt.get_grid's default latitude/longitude/time, regenerated by oracle/instellation_oracle.py)."""
+    for desc in ("column", "3d"):
+        v, dims, units = read_cache("TestInstellation-%s-0.cache" % desc)["zenith_angle"]
+        np.savez_compressed(os.path.join(OUT, "climt_cache_TestInstellation-%s.npz" % desc), zenith_angle=v, dims=np.array(",".join(dims)), units=np.array(units))
+        print("instellation cache", desc, v.shape)
+
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -177,3 +186,4 @@ if __name__ == "__main__":
     reference_cases()
     reference_rtrnmr_cases()
     reference_solvar_cases()
+    instellation_cases()

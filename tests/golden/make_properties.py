@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Extract the interface definition of the reference components (class attributes and the three
-property dictionaries of RRTMGLongwave / RRTMGShortwave, constructor keyword defaults) into
+property dictionaries of RRTMGLongwave / RRTMGShortwave / Instellation, constructor keyword defaults) into
 tests/golden/reference_interface.json by parsing the reference source with `ast` (sympl is not installed,
 so the modules cannot be imported).  Run in the build container only."""
 import ast
@@ -12,7 +12,8 @@ OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "reference_interf
 
 res = {}
 for key, path, cls in (("RRTMGShortwave", "climt/_components/rrtmg/sw/component.py", "RRTMGShortwave"),
-                       ("RRTMGLongwave", "climt/_components/rrtmg/lw/component.py", "RRTMGLongwave")):
+                       ("RRTMGLongwave", "climt/_components/rrtmg/lw/component.py", "RRTMGLongwave"),
+                       ("Instellation", "climt/_components/instellation/component.py", "Instellation")):
     tree = ast.parse(open(os.path.join(REF, path)).read())
     node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
     entry = {}

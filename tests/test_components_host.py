@@ -26,7 +26,7 @@ def emulated_context(monkeypatch):
 REF_IF = json.load(open(os.path.join(GOLDEN, "reference_interface.json")))
 
 
-@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave])
+@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave, climt_amd.Instellation])
 def test_interface_identical_to_reference(cls):
     """class attributes, the three property dicts and constructor defaults equal the reference's."""
     ref = REF_IF[cls.__name__]
@@ -149,3 +149,13 @@ def test_unit_conversion_of_the_sympl_standin():
     assert sc.convert_units(5.0, "\xb5m", "micrometer") == 5.0
     with pytest.raises(ValueError):
         sc.convert_units(1.0, "Pa", "K")
+
+
+def test_instellation_time_arithmetic_matches_oracle():
+    """days since 2000-01-01 12:00 (the only host arithmetic of the Instellation drop-in), incl. sub-second times."""
+    import datetime
+    from climt_amd import instellation
+    from oracle import instellation_oracle as orc
+    for t in (datetime.datetime(2000, 1, 1), datetime.datetime(1999, 12, 31, 23, 59, 59, 250000), datetime.datetime(2031, 7, 4, 6, 30),
+              datetime.datetime(1850, 3, 1, 12)):
+        assert instellation.days_from_2000(t) == orc.days_from_2000(t)

@@ -59,6 +59,46 @@ def test_sw_solar_variability_methods_vs_reference_fixture(gpu_ctx):
             assert maxdiff(out[k], z["case%02d/%s" % (i, k)]) <= TIGHT, (case, k)
 
 
+def test_zenith_angle_kernel_vs_oracle_and_reference_caches(gpu_ctx):
+    """rrtmg_hip_zenith_angle (climt Instellation on the device) against the numpy restatement -- which the CPU suite pins
+    to the reference's caches -- on the cached grids and on 20000 random points / times, host and device pointers.
+    Tolerance 1e-9 rad (arccos near the sub-solar point amplifies the last-place differences of sin/cos)."""
+    import datetime
+    from climt_amd import _hip
+    from oracle import instellation_oracle as orc
+    for desc, nx, ny in (("column", None, None), ("3d", 32, 16)):
+        exp = np.load(os.path.join(ROOT, "tests", "golden", "climt_cache_TestInstellation-%s.npz" % desc))["zenith_angle"]
+        lat, lon = orc.default_grid(nx, ny)
+        z = gpu_ctx.zenith_angle(lat, lon, orc.julian_centuries(orc.DEFAULT_TIME))
+        assert np.abs(z - exp).max() <= 1.0e-8      # the reference's own criterion
+        assert np.abs(z - exp).max() <= 1.0e-12
+    rng = np.random.default_rng(3)
+    lat, lon = rng.uniform(-90, 90, 20000), rng.uniform(-180, 540, 20000)
+    for t in (datetime.datetime(2000, 6, 21, 12), datetime.datetime(2017, 3, 20, 10, 28), datetime.datetime(1975, 12, 21, 3)):
+        ref = orc.zenith_angle(lat, lon, t)
+        z = gpu_ctx.zenith_angle(lat, lon, orc.julian_centuries(t))
+        assert np.abs(z - ref).max() <= 1.0e-9 and (ref < np.pi / 2).sum() > 5000
+        dl, dn, dz = _hip.DeviceArray.from_host(lat), _hip.DeviceArray.from_host(lon), _hip.DeviceArray((20000,))
+        gpu_ctx.zenith_angle(dl.ptr, dn.ptr, orc.julian_centuries(t), out=dz.ptr, memspace=1, ncol=20000)
+        assert np.array_equal(dz.download(), z)
+
+
+def test_instellation_component_reproduces_reference_cache():
+    """climt_amd.Instellation (sympl-style call on a state of DataArrays) against TestInstellation-3d-0.cache."""
+    import climt_amd
+    from climt_amd._sympl_compat import DataArray
+    from oracle import instellation_oracle as orc
+    exp = np.load(os.path.join(ROOT, "tests", "golden", "climt_cache_TestInstellation-3d.npz"))["zenith_angle"]
+    lat, lon = orc.default_grid(32, 16)
+    state = {"time": orc.DEFAULT_TIME,
+             "latitude": DataArray(lat, dims=["lat", "lon"], attrs={"units": "degrees_north"}),
+             "longitude": DataArray(lon, dims=["lat", "lon"], attrs={"units": "degrees_east"})}
+    out = climt_amd.Instellation()(state)
+    assert list(out) == ["zenith_angle"] and out["zenith_angle"].attrs["units"] == "radians"
+    assert tuple(out["zenith_angle"].dims) == ("lat", "lon")
+    assert np.abs(out["zenith_angle"].values - exp).max() <= 1.0e-8
+
+
 def test_native_library_is_what_runs(gpu_ctx):
     """The HIP extension, in-tree, is loaded in this process (no eager/CPU fallback exists)."""
     maps = open("/proc/self/maps").read()

@@ -82,3 +82,15 @@ def test_oracle_against_live_reference_library():
     r = rl.fluxes(c, mcica=True)
     o = port.PortLW().fluxes(c, mcica=True)
     assert max(maxdiff(o[k], r[k]) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc", "duflx_dt", "duflxc_dt")) <= 1e-9
+
+
+@pytest.mark.parametrize("desc,nx,ny", [("column", None, None), ("3d", 32, 16)])
+def test_instellation_oracle_reproduces_reference_caches(desc, nx, ny):
+    """oracle/instellation_oracle.py against the reference's own golden caches TestInstellation-{column,3d}-0.cache
+    (criterion of the reference's tests: 1e-8), on climt.get_grid's default latitude / longitude / time."""
+    from oracle import instellation_oracle as orc
+    exp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "climt_cache_TestInstellation-%s.npz" % desc))["zenith_angle"]
+    lat, lon = orc.default_grid(nx, ny)
+    z = orc.zenith_angle(lat, lon, orc.DEFAULT_TIME)
+    assert z.shape == exp.shape and np.abs(z - exp).max() <= 1.0e-8
+    assert np.abs(z - exp).max() <= 1.0e-14
