@@ -70,6 +70,7 @@ def load_library():
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
     lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_zenith_angle.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _vp]
+    lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
@@ -161,6 +162,15 @@ class Context:
         z = np.empty(lat.shape) if out is None else out
         self._ck(self.lib.rrtmg_hip_zenith_angle(self.h, lat.size, 0, lat.ctypes.data, lon.ctypes.data, float(julian_centuries), z.ctypes.data))
         return z
+
+    def solar_insolation(self, lat, lon, sin_delta, cos_delta, fractional_day, irradiance):
+        """(zenith angle, insolation) of every column (host arrays): per-column part of BergerSolarInsolation."""
+        lat = np.ascontiguousarray(lat, dtype=np.float64)
+        lon = np.ascontiguousarray(lon, dtype=np.float64)
+        z, s = np.empty(lat.shape), np.empty(lat.shape)
+        self._ck(self.lib.rrtmg_hip_solar_insolation(self.h, lat.size, 0, lat.ctypes.data, lon.ctypes.data, float(sin_delta), float(cos_delta),
+                                                     float(fractional_day), float(irradiance), z.ctypes.data, s.ctypes.data))
+        return z, s
 
     def set_deferred(self, on=True):
         """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams."""

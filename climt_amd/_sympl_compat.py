@@ -160,7 +160,8 @@ except ImportError:
             out = {}
             for name, arr in arrays.items():
                 prop = properties[name]
-                dims = prop.get("dims") or self.input_properties[name]["dims"]
+                dims = prop["dims"] if prop.get("dims") is not None else self.input_properties[name]["dims"]
+                arr = np.asarray(arr)
                 shape, names = [], []
                 for d, n in zip(dims, arr.shape):
                     if d == "*":

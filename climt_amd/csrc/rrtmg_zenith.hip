@@ -51,9 +51,53 @@ __global__ void __launch_bounds__(256) zenith_kernel(int n, const double *lat_de
   zenith[i] = z;
 }
 
+// climt BergerSolarInsolation, per-column part (berger_solar_insolation.py:671-676): hour angle from the fraction of
+// the day and the longitude, cos(mu), zenith angle and insolation.  The latitude VALUE (degrees) goes into sin/cos as
+// it is -- the reference does so (:673) and its golden caches pin it.
+__global__ void __launch_bounds__(256) insolation_kernel(int n, const double *lat, const double *lon, double sin_delta, double cos_delta,
+                                                         double fractional_day, double irradiance, double *zenith, double *insolation) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double pi = 3.14159265358979323846;
+  const double H = 2 * pi * (fractional_day + lon[i] / 360.0);
+  const double cos_mu = sin(lat[i]) * sin_delta - cos(lat[i]) * cos_delta * cos(H);
+  zenith[i] = acos(cos_mu);
+  insolation[i] = irradiance * cos_mu;
+}
+
 }  // namespace rrtmg
 
 using namespace rrtmg;
+
+extern "C" int rrtmg_hip_solar_insolation(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat, const double *lon, double sin_delta,
+                                          double cos_delta, double fractional_day, double irradiance, double *zenith, double *insolation) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (ncol <= 0 || !lat || !lon || !zenith || !insolation) return ctx->fail(RRTMG_ERR_ARG, "solar_insolation: bad argument");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t bytes = (size_t)ncol * sizeof(double);
+  const double *dlat = lat, *dlon = lon;
+  double *dz = zenith, *di = insolation;
+  if (memspace == 0) {
+    double *a = (double *)ctx->buf("zen.lat", bytes), *b = (double *)ctx->buf("zen.lon", bytes);
+    dz = (double *)ctx->buf("zen.out", bytes); di = (double *)ctx->buf("zen.ins", bytes);
+    if (!a || !b || !dz || !di) return ctx->status;
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a, lat, bytes, hipMemcpyHostToDevice, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(b, lon, bytes, hipMemcpyHostToDevice, s));
+    dlat = a; dlon = b;
+  }
+  hipLaunchKernelGGL(insolation_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, dlat, dlon, sin_delta, cos_delta, fractional_day,
+                     irradiance, dz, di);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (memspace == 0) {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(zenith, dz, bytes, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(insolation, di, bytes, hipMemcpyDeviceToHost, s));
+  }
+  if (ctx->deferred && memspace == 1) return RRTMG_OK;
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  return RRTMG_OK;
+}
 
 extern "C" int rrtmg_hip_zenith_angle(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat_deg, const double *lon_deg,
                                       double julian_centuries, double *zenith) {

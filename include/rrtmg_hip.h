@@ -106,6 +106,14 @@ long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long cap
 int rrtmg_hip_zenith_angle(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat_deg, const double *lon_deg,
                            double julian_centuries, double *zenith);
 
+/* Per-column part of climt's BergerSolarInsolation (climt/_components/berger_solar_insolation.py:671-676):
+ * zenith[i] = arccos(cos_mu), insolation[i] = irradiance * cos_mu with cos_mu = sin(lat) sin_delta - cos(lat) cos_delta
+ * cos(2 pi (fractional_day + lon / 360)).  lat is used as given (the reference passes degrees into sin/cos, :673);
+ * sin_delta / cos_delta of the solar declination and irradiance = S0 / rho^2 come from the host-side orbital series
+ * (:579-668, climt_amd/berger.py). */
+int rrtmg_hip_solar_insolation(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat, const double *lon, double sin_delta,
+                               double cos_delta, double fractional_day, double irradiance, double *zenith, double *insolation);
+
 /* ---- shortwave ------------------------------------------------------------------------ */
 typedef struct rrtmg_sw_args {
   int32_t ncol, nlay;

@@ -176,6 +176,14 @@ def instellation_cases():
         print("instellation cache", desc, v.shape)
 
 
+def berger_cases():
+    """climt_cache_TestBergerSolarInsolation-{column,3d}.npz: the expected outputs of the reference's golden caches."""
+    for desc in ("column", "3d"):
+        c = read_cache("TestBergerSolarInsolation-%s-0.cache" % desc)
+        np.savez_compressed(os.path.join(OUT, "climt_cache_TestBergerSolarInsolation-%s.npz" % desc), **{k: v[0] for k, v in c.items()})
+        print("berger cache", desc, {k: v[0].shape for k, v in c.items()})
+
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -187,3 +195,4 @@ if __name__ == "__main__":
     reference_rtrnmr_cases()
     reference_solvar_cases()
     instellation_cases()
+    berger_cases()

@@ -26,7 +26,7 @@ def emulated_context(monkeypatch):
 REF_IF = json.load(open(os.path.join(GOLDEN, "reference_interface.json")))
 
 
-@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave, climt_amd.Instellation])
+@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave, climt_amd.Instellation, climt_amd.BergerSolarInsolation])
 def test_interface_identical_to_reference(cls):
     """class attributes, the three property dicts and constructor defaults equal the reference's."""
     ref = REF_IF[cls.__name__]
@@ -159,3 +159,16 @@ def test_instellation_time_arithmetic_matches_oracle():
     for t in (datetime.datetime(2000, 1, 1), datetime.datetime(1999, 12, 31, 23, 59, 59, 250000), datetime.datetime(2031, 7, 4, 6, 30),
               datetime.datetime(1850, 3, 1, 12)):
         assert instellation.days_from_2000(t) == orc.days_from_2000(t)
+
+
+def test_berger_orbital_series_and_time_helpers_match_oracle():
+    """The host part of the BergerSolarInsolation drop-in (orbital series of a year, vernal-equinox year fraction, day
+    fraction) against the oracle's restatement, bit for bit (both are numpy on the same packed tables)."""
+    import datetime
+    from climt_amd import berger
+    from oracle import berger_oracle as orc
+    for year in (1950, 2000, 2017, 1850, 2300):
+        assert berger.get_orbital_parameters(float(year - 1950)) == orc.orbital_parameters(float(year - 1950))
+    for t in (datetime.datetime(2000, 1, 1), datetime.datetime(2000, 3, 20, 12), datetime.datetime(2016, 2, 29, 23, 59, 59), datetime.datetime(1999, 12, 31, 6)):
+        assert berger.years_since_vernal_equinox(t) == orc.years_since_vernal_equinox(t)
+        assert berger.fractional_day(t) == orc.fractional_day(t)

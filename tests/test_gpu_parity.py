@@ -99,6 +99,34 @@ def test_instellation_component_reproduces_reference_cache():
     assert np.abs(out["zenith_angle"].values - exp).max() <= 1.0e-8
 
 
+def test_berger_solar_insolation_component_vs_caches_and_oracle():
+    """climt_amd.BergerSolarInsolation (host orbital series + device per-column kernel) against the reference's golden
+    caches (1e-8, its own criterion) and, on random points and times, against the oracle."""
+    import datetime
+    import climt_amd
+    from climt_amd._sympl_compat import DataArray
+    from oracle import berger_oracle as brg, instellation_oracle as orc
+    comp = climt_amd.BergerSolarInsolation()
+    for desc, nx, ny in (("column", None, None), ("3d", 32, 16)):
+        exp = np.load(os.path.join(ROOT, "tests", "golden", "climt_cache_TestBergerSolarInsolation-%s.npz" % desc))
+        lat, lon = orc.default_grid(nx, ny)
+        state = {"time": orc.DEFAULT_TIME, "latitude": DataArray(lat, dims=["lat", "lon"], attrs={"units": "degrees_north"}),
+                 "longitude": DataArray(lon, dims=["lat", "lon"], attrs={"units": "degrees_east"})}
+        out = comp(state)
+        assert set(out) == set(exp.files)
+        for k in exp.files:
+            assert np.abs(np.asarray(out[k].values) - exp[k]).max() <= 1.0e-8, k
+    rng = np.random.default_rng(8)
+    lat, lon = rng.uniform(-90, 90, (50, 40)), rng.uniform(0, 360, (50, 40))
+    for t in (datetime.datetime(2003, 9, 23, 17, 45), datetime.datetime(1984, 6, 21)):
+        state = {"time": t, "latitude": DataArray(lat, dims=["lat", "lon"], attrs={"units": "degrees_north"}),
+                 "longitude": DataArray(lon, dims=["lat", "lon"], attrs={"units": "degrees_east"})}
+        out = comp(state)
+        ref = brg.solar_parameters(lat, lon, t, 1367.0)
+        assert np.abs(out["solar_insolation"].values - ref[0]).max() <= 1.0e-9
+        assert np.abs(out["solar_zenith_angle"].values - ref[1]).max() <= 1.0e-9   # arccos conditioning near cos_mu = +-1
+
+
 def test_native_library_is_what_runs(gpu_ctx):
     """The HIP extension, in-tree, is loaded in this process (no eager/CPU fallback exists)."""
     maps = open("/proc/self/maps").read()

@@ -94,3 +94,16 @@ def test_instellation_oracle_reproduces_reference_caches(desc, nx, ny):
     z = orc.zenith_angle(lat, lon, orc.DEFAULT_TIME)
     assert z.shape == exp.shape and np.abs(z - exp).max() <= 1.0e-8
     assert np.abs(z - exp).max() <= 1.0e-14
+
+
+@pytest.mark.parametrize("desc,nx,ny", [("column", None, None), ("3d", 32, 16)])
+def test_berger_oracle_reproduces_reference_caches(desc, nx, ny):
+    """oracle/berger_oracle.py against TestBergerSolarInsolation-{column,3d}-0.cache (reference criterion 1e-8)."""
+    from oracle import berger_oracle as brg, instellation_oracle as orc
+    exp = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "climt_cache_TestBergerSolarInsolation-%s.npz" % desc))
+    lat, lon = orc.default_grid(nx, ny)
+    got = dict(zip(("solar_insolation", "solar_zenith_angle", "obliquity", "eccentricity", "normalized_earth_sun_distance"),
+                   brg.solar_parameters(lat, lon, orc.DEFAULT_TIME, 1367.0)))
+    for k in got:
+        assert np.abs(got[k] - exp[k]).max() <= 1.0e-8, k
+        assert np.abs(got[k] - exp[k]).max() <= 1.0e-11, k
