@@ -40,6 +40,16 @@ class LwArgs(C.Structure):
                                       "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()])
 
 
+SLAB_IN = ("sw_down lw_down sw_up lw_up lh sh up_heat_soil heat_flux_sea_ice sea_water_dens surf_dens heat_cap_soil surf_therm_cap "
+           "ocean_mix_thick soil_layer_thick ocean_heat_transport").split()
+
+
+class SlabArgs(C.Structure):
+    """mirrors `rrtmg_slab_args` (include/rrtmg_hip.h), field for field"""
+    _fields_ = [(n, _vp) for n in ("sw_down lw_down sw_up lw_up lh sh area_type up_heat_soil heat_flux_sea_ice sea_water_dens surf_dens "
+                                   "heat_cap_soil surf_therm_cap ocean_mix_thick soil_layer_thick ocean_heat_transport tend_ts depth").split()]
+
+
 _lib = None
 
 
@@ -70,6 +80,7 @@ def load_library():
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
     lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_zenith_angle.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _vp]
+    lib.rrtmg_hip_slab_surface.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(SlabArgs)]
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
@@ -171,6 +182,22 @@ class Context:
         self._ck(self.lib.rrtmg_hip_solar_insolation(self.h, lat.size, 0, lat.ctypes.data, lon.ctypes.data, float(sin_delta), float(cos_delta),
                                                      float(fractional_day), float(irradiance), z.ctypes.data, s.ctypes.data))
         return z, s
+
+    def slab_surface(self, area_type, **arrays):
+        """Kernel of climt SlabSurface on host arrays: -> (surface temperature tendency, slab depth).  `arrays`: SLAB_IN."""
+        a = SlabArgs()
+        keep = [np.ascontiguousarray(area_type, dtype=np.int32)]
+        a.area_type = keep[0].ctypes.data
+        n = keep[0].size
+        for k in SLAB_IN:
+            v = np.ascontiguousarray(arrays[k], dtype=np.float64)
+            assert v.size == n, k
+            keep.append(v)
+            setattr(a, k, v.ctypes.data)
+        tend, depth = np.empty(n), np.empty(n)
+        a.tend_ts, a.depth = tend.ctypes.data, depth.ctypes.data
+        self._ck(self.lib.rrtmg_hip_slab_surface(self.h, n, 0, C.byref(a)))
+        return tend, depth
 
     def set_deferred(self, on=True):
         """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams."""

@@ -67,7 +67,8 @@ except ImportError:
     _UNIT_ALIASES = {
         "mbar": "hPa", "millibar": "hPa", "degK": "K", "kelvin": "K", "dimensionless": "1", "": "1", "g/g": "1", "kg/kg": "1",
         "kg kg^-1": "1", "g g^-1": "1", "mole/mole": "1", "micrometer": "um", "micron": "um", "µm": "um", "\xb5m": "um",
-        "kg/m**2": "kg m^-2", "kg/m^2": "kg m^-2", "g/m^2": "g m^-2", "W/m^2": "W m^-2", "K/day": "K day^-1",
+        "kg/m**2": "kg m^-2", "kg/m^2": "kg m^-2", "g/m^2": "g m^-2", "W/m^2": "W m^-2", "W/m**2": "W m^-2", "K/day": "K day^-1",
+        "J/(degK*kg)": "J kg^-1 K^-1", "J kg^-1 degK^-1": "J kg^-1 K^-1", "J/kg/K": "J kg^-1 K^-1", "kg/m**3": "kg m^-3", "kg/m^3": "kg m^-3",
         "degK day^-1": "K day^-1", "degK/day": "K day^-1", "radian": "radians", "rad": "radians",
     }
     _TO_BASE = {"hPa": ("Pa", 100.0), "Pa": ("Pa", 1.0), "kPa": ("Pa", 1000.0), "kg m^-2": ("kg m^-2", 1.0), "g m^-2": ("kg m^-2", 1.e-3),
@@ -121,8 +122,9 @@ except ImportError:
                 if name not in state:
                     raise KeyError("state is missing input quantity %r" % name)
                 da = state[name]
-                values, dims = np.asarray(da.values, dtype=np.float64), tuple(da.dims)
-                values = convert_units(values, da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
+                values, dims = np.asarray(da.values), tuple(da.dims)
+                if values.dtype.kind in "fiub":     # numeric; string quantities (area_type) pass through
+                    values = convert_units(values.astype(np.float64), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
                 want = list(prop["dims"])
                 named = [d for d in want if d != "*"]
                 for d in named:

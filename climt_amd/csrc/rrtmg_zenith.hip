@@ -65,9 +65,80 @@ __global__ void __launch_bounds__(256) insolation_kernel(int n, const double *la
   insolation[i] = irradiance * cos_mu;
 }
 
+// Downstream of the radiation path: kernel of climt's SlabSurface (slab_surface.py:440-517, default configuration),
+// one thread per column.  The four flux arguments are the SURFACE rows of the radiation outputs -- row 0 of the
+// [level][column] arrays, so a device-resident radiation step feeds it without a copy.
+struct SlabArgs {
+  const double *sw_down, *lw_down, *sw_up, *lw_up, *lh, *sh;
+  const int32_t *area_type;   // land 0, land_ice 1, sea 2, sea_ice 3
+  const double *up_heat_soil, *heat_flux_sea_ice, *sea_water_dens, *surf_dens, *heat_cap_soil, *surf_therm_cap;
+  const double *ocean_mix_thick, *soil_layer_thick, *ocean_heat_transport;
+  double *tend_ts, *depth;
+};
+__global__ void __launch_bounds__(256) slab_surface_kernel(int n, SlabArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double net_heat_flux = a.sw_down[i] + a.lw_down[i] - a.sw_up[i] - a.lw_up[i] - a.sh[i] - a.lh[i];
+  const int at = a.area_type[i];
+  const bool land_mask = (at == 0) || (at == 1), sea_mask = (at == 2) || (at == 3), land_ice_mask = at == 1, sea_ice_mask = at == 3;
+  if (land_ice_mask) net_heat_flux = -a.up_heat_soil[i];
+  else if (sea_ice_mask) net_heat_flux = a.heat_flux_sea_ice[i];
+  if (sea_mask && !sea_ice_mask) net_heat_flux = net_heat_flux + a.ocean_heat_transport[i];
+  double final_dens, d;
+  if (sea_mask) { final_dens = a.sea_water_dens[i]; d = a.ocean_mix_thick[i]; }
+  else { final_dens = a.surf_dens[i]; d = land_mask ? a.soil_layer_thick[i] : 0.0; }
+  const double final_therm_cap = land_mask ? a.heat_cap_soil[i] : a.surf_therm_cap[i];
+  a.depth[i] = d;
+  const double heat_cap_slab = (final_dens * d) * final_therm_cap;
+  double val = heat_cap_slab != 0 ? net_heat_flux / heat_cap_slab : 0.0;
+  if (land_ice_mask || sea_ice_mask) val = 0.0;
+  a.tend_ts[i] = val;
+}
+
 }  // namespace rrtmg
 
 using namespace rrtmg;
+
+extern "C" int rrtmg_hip_slab_surface(rrtmg_ctx *ctx, int ncol, int memspace, const rrtmg_slab_args *h) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (ncol <= 0 || !h) return ctx->fail(RRTMG_ERR_ARG, "slab_surface: bad argument");
+  const double *const in[15] = {h->sw_down, h->lw_down, h->sw_up, h->lw_up, h->lh, h->sh, h->up_heat_soil, h->heat_flux_sea_ice,
+                                h->sea_water_dens, h->surf_dens, h->heat_cap_soil, h->surf_therm_cap, h->ocean_mix_thick,
+                                h->soil_layer_thick, h->ocean_heat_transport};
+  for (int k = 0; k < 15; ++k)
+    if (!in[k]) return ctx->fail(RRTMG_ERR_ARG, "slab_surface: input array %d is NULL", k);
+  if (!h->area_type || !h->tend_ts || !h->depth) return ctx->fail(RRTMG_ERR_ARG, "slab_surface: area_type / output array is NULL");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t bytes = (size_t)ncol * sizeof(double);
+  const double *dev[15];
+  const int32_t *dat = h->area_type;
+  double *dt = h->tend_ts, *dd = h->depth;
+  if (memspace == 0) {
+    double *slab = (double *)ctx->buf("slab.io", 17 * bytes);
+    int32_t *at = (int32_t *)ctx->buf("slab.at", (size_t)ncol * 4);
+    if (!slab || !at) return ctx->status;
+    for (int k = 0; k < 15; ++k) {
+      RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(slab + (size_t)k * ncol, in[k], bytes, hipMemcpyHostToDevice, s));
+      dev[k] = slab + (size_t)k * ncol;
+    }
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(at, h->area_type, (size_t)ncol * 4, hipMemcpyHostToDevice, s));
+    dat = at; dt = slab + (size_t)15 * ncol; dd = slab + (size_t)16 * ncol;
+  } else {
+    for (int k = 0; k < 15; ++k) dev[k] = in[k];
+  }
+  SlabArgs a{dev[0], dev[1], dev[2], dev[3], dev[4], dev[5], dat, dev[6], dev[7], dev[8], dev[9], dev[10], dev[11], dev[12], dev[13], dev[14], dt, dd};
+  hipLaunchKernelGGL(slab_surface_kernel, dim3((ncol + 255) / 256), dim3(256), 0, s, ncol, a);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (memspace == 0) {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(h->tend_ts, dt, bytes, hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(h->depth, dd, bytes, hipMemcpyDeviceToHost, s));
+  }
+  if (ctx->deferred && memspace == 1) return RRTMG_OK;
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  return RRTMG_OK;
+}
 
 extern "C" int rrtmg_hip_solar_insolation(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat, const double *lon, double sin_delta,
                                           double cos_delta, double fractional_day, double irradiance, double *zenith, double *insolation) {

@@ -114,6 +114,20 @@ int rrtmg_hip_zenith_angle(rrtmg_ctx *ctx, int ncol, int memspace, const double 
 int rrtmg_hip_solar_insolation(rrtmg_ctx *ctx, int ncol, int memspace, const double *lat, const double *lon, double sin_delta,
                                double cos_delta, double fractional_day, double irradiance, double *zenith, double *insolation);
 
+/* ---- downstream of the radiation path: slab surface energy balance (climt SlabSurface) ---------- */
+/* Kernel of climt/_components/slab_surface.py:440-517 (default configuration, include_ekman=False): surface
+ * temperature tendency (K s^-1) and slab depth (m) per column.  The four flux pointers are the SURFACE rows (row 0 of
+ * the [level][column] radiation outputs); area_type codes: land 0, land_ice 1, sea 2, sea_ice 3 (slab_surface.py:9). */
+typedef struct rrtmg_slab_args {
+  const double *sw_down, *lw_down, *sw_up, *lw_up;      /* surface fluxes W m^-2 */
+  const double *lh, *sh;                                /* surface upward latent / sensible heat flux */
+  const int32_t *area_type;
+  const double *up_heat_soil, *heat_flux_sea_ice, *sea_water_dens, *surf_dens, *heat_cap_soil, *surf_therm_cap;
+  const double *ocean_mix_thick, *soil_layer_thick, *ocean_heat_transport;
+  double *tend_ts, *depth;                              /* outputs */
+} rrtmg_slab_args;
+int rrtmg_hip_slab_surface(rrtmg_ctx *ctx, int ncol, int memspace, const rrtmg_slab_args *args);
+
 /* ---- shortwave ------------------------------------------------------------------------ */
 typedef struct rrtmg_sw_args {
   int32_t ncol, nlay;

@@ -184,6 +184,30 @@ def berger_cases():
         print("berger cache", desc, {k: v[0].shape for k, v in c.items()})
 
 
+def slab_surface_cases():
+    """climt_cache_TestSlabSurface-{column,3d}.npz: default-state inputs (from the *_stepping-1 caches, which hold the full
+    state) and the expected tendency / diagnostics of the reference's golden caches."""
+    for desc in ("column", "3d"):
+        state = read_cache("TestSlabSurface-%s_stepping-1.cache" % desc)
+        save = {}
+        for k, (v, dims, units) in state.items():
+            if k == "time":
+                continue
+            if k == "area_type":      # char array (..., 100) -> strings
+                v = np.array([b"".join(x).decode().strip() for x in v.reshape(-1, v.shape[-1])]).reshape(v.shape[:-1])
+                dims = dims[:-1]
+            save["state/%s/values" % k] = v
+            save["state/%s/dims" % k] = np.array(",".join(dims))
+            save["state/%s/units" % k] = np.array(units)
+        for grp, idx in (("tend", 0), ("diag", 1)):
+            for k, (v, dims, units) in read_cache("TestSlabSurface-%s-%d.cache" % (desc, idx)).items():
+                save["%s/%s/values" % (grp, k)] = v
+                save["%s/%s/dims" % (grp, k)] = np.array(",".join(dims))
+                save["%s/%s/units" % (grp, k)] = np.array(units)
+        np.savez_compressed(os.path.join(OUT, "climt_cache_TestSlabSurface-%s.npz" % desc), **save)
+        print("slab surface cache", desc, len(save))
+
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -196,3 +220,4 @@ if __name__ == "__main__":
     reference_solvar_cases()
     instellation_cases()
     berger_cases()
+    slab_surface_cases()

@@ -14,7 +14,8 @@ res = {}
 for key, path, cls in (("RRTMGShortwave", "climt/_components/rrtmg/sw/component.py", "RRTMGShortwave"),
                        ("RRTMGLongwave", "climt/_components/rrtmg/lw/component.py", "RRTMGLongwave"),
                        ("Instellation", "climt/_components/instellation/component.py", "Instellation"),
-                       ("BergerSolarInsolation", "climt/_components/berger_solar_insolation.py", "BergerSolarInsolation")):
+                       ("BergerSolarInsolation", "climt/_components/berger_solar_insolation.py", "BergerSolarInsolation"),
+                       ("SlabSurface", "climt/_components/slab_surface.py", "SlabSurface")):
     tree = ast.parse(open(os.path.join(REF, path)).read())
     node = [n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == cls][0]
     entry = {}

@@ -26,7 +26,8 @@ def emulated_context(monkeypatch):
 REF_IF = json.load(open(os.path.join(GOLDEN, "reference_interface.json")))
 
 
-@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave, climt_amd.Instellation, climt_amd.BergerSolarInsolation])
+@pytest.mark.parametrize("cls", [climt_amd.RRTMGShortwave, climt_amd.RRTMGLongwave, climt_amd.Instellation, climt_amd.BergerSolarInsolation,
+                                 climt_amd.SlabSurface])
 def test_interface_identical_to_reference(cls):
     """class attributes, the three property dicts and constructor defaults equal the reference's."""
     ref = REF_IF[cls.__name__]

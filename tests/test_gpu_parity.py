@@ -127,6 +127,35 @@ def test_berger_solar_insolation_component_vs_caches_and_oracle():
         assert np.abs(out["solar_zenith_angle"].values - ref[1]).max() <= 1.0e-9   # arccos conditioning near cos_mu = +-1
 
 
+def test_slab_surface_kernel_and_component(gpu_ctx):
+    """rrtmg_hip_slab_surface against the oracle on random columns of all four area types (bit-exact: plain fp64
+    arithmetic), and climt_amd.SlabSurface against the reference's golden caches."""
+    import climt_amd
+    from climt_amd._lib import SLAB_IN
+    from helpers import load_cache_case
+    from oracle import slab_surface_oracle as orc
+    rng = np.random.default_rng(4)
+    n = 5000
+    arrays = {k: rng.uniform(0.0, 500.0, n) for k in SLAB_IN}
+    arrays.update(sea_water_dens=rng.uniform(1000, 1050, n), surf_dens=rng.uniform(900, 2500, n), heat_cap_soil=rng.uniform(800, 2500, n),
+                  surf_therm_cap=rng.uniform(2000, 4200, n), ocean_mix_thick=rng.uniform(0, 100, n), soil_layer_thick=rng.uniform(0, 5, n))
+    arrays["ocean_mix_thick"][::7] = 0.0        # zero heat capacity -> tendency 0
+    at = rng.integers(0, 4, n).astype(np.int32)
+    t, d = gpu_ctx.slab_surface(at, **arrays)
+    et, ed = orc.slab_surface(*(arrays[k] for k in SLAB_IN[:6]), at, *(arrays[k] for k in SLAB_IN[6:]))
+    assert np.array_equal(d, ed) and np.array_equal(t, et)
+    comp = climt_amd.SlabSurface()
+    for desc in ("column", "3d"):
+        state, tend, diag = load_cache_case("TestSlabSurface", desc)
+        # the cache keeps fluxes as (interface_levels, lat, lon); the component's dims are ["*", "interface_levels"]
+        got_t, got_d = comp(state)
+        assert set(got_t) == set(tend) and set(got_d) == set(diag)
+        for got, exp in ((got_t, tend), (got_d, diag)):
+            for k in exp:
+                g = np.transpose(got[k].values, [got[k].dims.index(x) for x in exp[k].dims])
+                assert maxdiff(g, exp[k].values) <= 1.0e-8, k
+
+
 def test_native_library_is_what_runs(gpu_ctx):
     """The HIP extension, in-tree, is loaded in this process (no eager/CPU fallback exists)."""
     maps = open("/proc/self/maps").read()

@@ -107,3 +107,32 @@ def test_berger_oracle_reproduces_reference_caches(desc, nx, ny):
     for k in got:
         assert np.abs(got[k] - exp[k]).max() <= 1.0e-8, k
         assert np.abs(got[k] - exp[k]).max() <= 1.0e-11, k
+
+
+@pytest.mark.parametrize("desc", ["column", "3d"])
+def test_slab_surface_oracle_reproduces_reference_caches(desc):
+    """oracle/slab_surface_oracle.py on the cached default state (TestSlabSurface-*): tendency 0, depth 50 m, and a
+    hand-checked energy-balance case per area type."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import load_cache_case
+    from oracle import slab_surface_oracle as orc
+    state, tend, diag = load_cache_case("TestSlabSurface", desc)
+    v = lambda k: np.asarray(state[k].values, dtype=np.float64)
+    surf = lambda k: v(k)[0].ravel()                      # cache dims (interface_levels, lat, lon): level 0 = surface
+    at = np.vectorize(orc.AREA_MAP.get)(np.asarray(state["area_type"].values).astype(str)).ravel()
+    t, d = orc.slab_surface(surf("downwelling_shortwave_flux_in_air"), surf("downwelling_longwave_flux_in_air"),
+                            surf("upwelling_shortwave_flux_in_air"), surf("upwelling_longwave_flux_in_air"),
+                            v("surface_upward_latent_heat_flux").ravel(), v("surface_upward_sensible_heat_flux").ravel(), at,
+                            v("upward_heat_flux_at_ground_level_in_soil").ravel(), v("heat_flux_into_sea_water_due_to_sea_ice").ravel(),
+                            v("sea_water_density").ravel(), v("surface_material_density").ravel(), v("heat_capacity_of_soil").ravel(),
+                            v("surface_thermal_capacity").ravel(), v("ocean_mixed_layer_thickness").ravel(), v("soil_layer_thickness").ravel(),
+                            v("ocean_heat_transport_convergence").ravel())
+    assert np.abs(t - tend["surface_temperature"].values.ravel()).max() <= 1e-8
+    assert np.abs(d - diag["depth_of_slab_surface"].values.ravel()).max() <= 1e-8
+    # 100 W m^-2 into 50 m of sea water (1029 kg m^-3, 4181.3 J kg^-1 K^-1), soil (2 m, 1500, 2000), and the two ice types
+    one = np.ones(4)
+    t, d = orc.slab_surface(300 * one, 350 * one, 50 * one, 400 * one, 60 * one, 40 * one, np.array([2, 0, 1, 3]), 7 * one, 9 * one,
+                            1029 * one, 1500 * one, 2000 * one, 4181.3 * one, 50 * one, 2 * one, 25 * one)
+    assert np.allclose(t, [(100.0 + 25.0) / (1029 * 50 * 4181.3), 100.0 / (1500 * 2 * 2000), 0.0, 0.0], rtol=1e-15)
+    assert np.array_equal(d, [50.0, 2.0, 2.0, 50.0])
