@@ -896,14 +896,6 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   return s;
 }
 
-// McICA cloud-mask bit of (sub-column iw, layer l) / of the OR over all sub-columns
-RRTMG_HD bool lw_mask_bit(const LwDev &d, int iw, int col, int l) {
-  return (d.mask[((long)iw * d.nw + (l >> 6)) * d.ncol + col] >> (l & 63)) & 1ull;
-}
-RRTMG_HD bool lw_anymask_bit(const LwDev &d, int col, int l) {
-  return (d.anymask[(long)(l >> 6) * d.ncol + col] >> (l & 63)) & 1ull;
-}
-
 #ifdef RRTMG_ABL_UNIFORMLOOKUP
 #define LW_TBLIDX(x) (((int)(x)) & 1)
 #else
@@ -947,6 +939,22 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     secd_cb = d.secdiff[(long)cb * N + col];   // odcld(lay,ib) = secdiff(ib)*taucloud(lay,ib): cloud-band index
   }
 
+  // McICA cloud-mask words of the 64-layer block the sweeps are in (the G sub-columns of the item + the OR over
+  // all sub-columns): one 8-byte read per 64 layers instead of one per layer
+  uint64_t mw[G], aw = 0;
+  int mword = -1;
+#pragma unroll
+  for (int g = 0; g < G; ++g) mw[g] = 0;
+  auto mask_words = [&](int l) {
+    const int w = l >> 6;
+    if (w != mword) {
+#pragma unroll
+      for (int g = 0; g < G; ++g) mw[g] = d.mask[((long)(iw0 + g) * d.nw + w) * N + col];
+      aw = d.anymask[(long)w * N + col];
+      mword = w;
+    }
+  };
+
   // ---- downward sweep, lev = L .. 1 ---------------------------------------------------------
   double radld[G], radclrd[G], plfrac_bot[G];
   double cldrad[G], clrrad[G], radmr[G];   // rtrnmr: cloudy / clear parts of the radiance and the overlap carry `rad`
@@ -981,7 +989,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     double cfrac_band = 0.0, odcld_band = 0.0, efcl_band = 0.0;
     if (clouds) {
       if (d.mcica) {
-        icldlyr = lw_anymask_bit(d, col, l);
+        mask_words(l);
+        icldlyr = (aw >> (l & 63)) & 1ull;
         if (icldlyr) {
           odcld_band = secd * d.ctau[((long)ib * L + l) * N + col];
           efcl_band = (1.0 - exp(-odcld_band)) * 1.0;
@@ -1013,7 +1022,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
       if (icldlyr) {
         if (d.mcica) {
-          if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; odcld = odcld_band; efclfrac = efcl_band; }
+          if ((mw[g] >> (l & 63)) & 1ull) { cfrac = 1.0; odcld = odcld_band; efclfrac = efcl_band; }
         } else if (cld_band) {
           cfrac = cfrac_band; odcld = odcld_band; efclfrac = efcl_band;
         }
@@ -1152,7 +1161,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       double cfrac_band = 0.0, efcl_band = 0.0;
       if (clouds) {
         if (d.mcica) {
-          icldlyr = lw_anymask_bit(d, col, l);
+          mask_words(l);
+          icldlyr = (aw >> (l & 63)) & 1ull;
           if (icldlyr) {
             const double odcld = secd * d.ctau[((long)ib * L + l) * N + col];
             efcl_band = (1.0 - exp(-odcld)) * 1.0;
@@ -1182,7 +1192,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         double cfrac = 0.0, efclfrac = 0.0;
         if (icldlyr) {
           if (d.mcica) {
-            if (lw_mask_bit(d, iw0 + g, col, l)) { cfrac = 1.0; efclfrac = efcl_band; }
+            if ((mw[g] >> (l & 63)) & 1ull) { cfrac = 1.0; efclfrac = efcl_band; }
           } else if (cld_band) {
             cfrac = cfrac_band; efclfrac = efcl_band;
           }

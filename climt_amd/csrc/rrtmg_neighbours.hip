@@ -1,6 +1,10 @@
-// rrtmg_zenith.hip -- the producer on the upstream side of the shortwave path: climt's `Instellation` component
-// (zenith angle from latitude, longitude and time; /root/reference/climt/_components/instellation/component.py:85-191)
-// on the device, so that a radiation step can stay device-resident.
+// rrtmg_neighbours.hip -- the steps either side of the radiation path, so that a radiation step can stay
+// device-resident:
+//   upstream   rrtmg_hip_zenith_angle     climt Instellation          (instellation/component.py:85-191)
+//              rrtmg_hip_solar_insolation climt BergerSolarInsolation (berger_solar_insolation.py:671-676; orbital series on the host)
+//   downstream rrtmg_hip_slab_surface     climt SlabSurface           (slab_surface.py:440-517)
+//
+// Instellation: zenith angle from latitude, longitude and time.
 //   host  : sun position for the time of the call -- obliquity (:138-152), ecliptic longitude of the sun (:155-179),
 //           declination / right ascension (:90-99), Greenwich mean sidereal time (:182-191); scalars, same arithmetic
 //   device: one thread per column -- local hour angle, cos(mu) clamped to [-1, 1], arccos clamped to [-pi/2, pi/2]

@@ -813,12 +813,9 @@ template <int G> struct SwThreadCtx {
   const double *exp_tbl;   // transmittance table: the workgroup's LDS copy on the device, T.t + T.exp_tbl on the host
   bool cloudy[G];   // any cloud in (sub-)column g
   bool any_cloudy;
+  uint64_t mw[G];   // McICA cloud-mask words of the 64-layer block the sweep is in (one read per 64 layers)
+  int mword;
 };
-
-// McICA cloud-mask bit of (sub-column iw, layer l): one 8-byte read from the [iw][word][col] bit mask
-RRTMG_HD bool sw_mask_bit(const SwDev &d, int iw, int col, int l) {
-  return (d.mask[((long)iw * d.nw + (l >> 6)) * d.ncol + col] >> (l & 63)) & 1ull;
-}
 
 // taumol + delta scaling + reftra (+ cloud) for layer l and the G g-points of the item: everything the two
 // adding-method sweeps need.  The layer state, the species mixture, the interpolation weights and the table
@@ -827,7 +824,7 @@ RRTMG_HD bool sw_mask_bit(const SwDev &d, int iw, int col, int l) {
 // consume(g, clear, total) is called for each g-point right after its optics are ready, so that only ONE g-point's
 // ten layer operators are live at a time (register pressure).
 template <int BAND, int G, bool CLD, class Consume>
-RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<G> &c, int col, int l, Consume &&consume) {
+RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c, int col, int l, Consume &&consume) {
   const int L = d.nlay, N = d.ncol;
   const double *exp_tbl = c.exp_tbl;
   const double prmu0 = c.prmu0, rmu0 = c.rmu0;
@@ -844,6 +841,11 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
   bool lcld_band = false;
   if (CLD && c.any_cloudy) {
     if (!d.mcica) { zcloud = d.cldfr[i]; lcld_band = zcloud > 1.e-12; }
+    else if ((l >> 6) != c.mword) {
+      c.mword = l >> 6;
+#pragma unroll
+      for (int g = 0; g < G; ++g) c.mw[g] = d.mask[((long)(c.iw0 + g) * d.nw + c.mword) * N + col];
+    }
     ptauc = d.ctau[o];
     pomgc = d.cssa[o]; pasyc = d.casm[o];
   }
@@ -874,7 +876,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, const SwThreadCtx<
     ot = oc;
     bool lcld;
     double zc;
-    if (d.mcica) { lcld = sw_mask_bit(d, c.iw0 + g, col, l); zc = lcld ? 1.0 : 0.0; }
+    if (d.mcica) { lcld = (c.mw[g] >> (l & 63)) & 1ull; zc = lcld ? 1.0 : 0.0; }
     else { zc = zcloud; lcld = lcld_band; }
     const double ptc = (lcld || !d.mcica) ? ptauc : 0.0;
     if (lcld) {
@@ -930,8 +932,10 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   const double albp = vis ? d.asdir[col] : d.aldir[col];
   const double albd = vis ? d.asdif[col] : d.aldif[col];
   c.any_cloudy = false;
+  c.mword = -1;
 #pragma unroll
   for (int g = 0; g < G; ++g) {
+    c.mw[g] = 0;
     c.cloudy[g] = false;
     if (CLD && d.icld >= 1) {
       if (d.mcica) {
