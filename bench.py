@@ -222,7 +222,7 @@ def main():
         sw_ms, lw_ms = float(np.mean(ksw)), float(np.mean(klw))
         # the cloudy / clear-sky instantiation that does the work (names as rocprofv3 prints them)
         if sw_ms >= lw_ms:
-            kname, kms, bpc = "rrtmg::sw_solve_all_kernel" + ("<true>" if a.cloudy else "<false>"), sw_ms, (34 * L + 11) * 8
+            kname, kms, bpc = ("rrtmg::sw_solve_cloudy_kernel" if a.cloudy else "rrtmg::sw_solve_all_kernel<false>"), sw_ms, (34 * L + 11) * 8
         else:
             kname, kms, bpc = "rrtmg::lw_solve_all_kernel" + ("<true, false>" if a.cloudy else "<false, false>"), lw_ms, (56 * L + 22) * 8
         achieved = bpc * N / (kms * 1e-3) / 1e9
