@@ -31,16 +31,22 @@ RRTMG_HD void report_error(int *flag, int code) {
 #endif
 }
 
-// Quick fp64 division for the flux arithmetic of the hot loops: v_rcp_f64 + two Newton-Raphson steps
-// (<= ~1 ulp) instead of the 11-instruction IEEE sequence (div_scale x2, rcp, 6 fma, div_fmas, div_fixup) --
-// divisions were ~60 % of the VALU instructions of the solve kernels.  Operands here are O(1e-20..1e20) and
-// never zero/inf/denormal.  NOT used where an integer is derived from the quotient (table indices, specparm ->
-// js): those keep the correctly rounded `/`.  On the host (tests/emu) it is the plain division.
+// Quick fp64 division for the flux arithmetic of the shortwave hot loops: v_rcp_f64 + ONE Newton-Raphson step
+// (relative error <= 2.2e-15, i.e. ~20 ulp; 4 instructions) instead of the 11-instruction IEEE sequence (div_scale x2,
+// rcp, 6 fma, div_fmas, div_fixup) -- divisions were ~60 % of the VALU instructions of the solve kernels, which are
+// VALU-issue bound.  Fluxes move by ~1e-10 W m-2 (bar: 1e-2).  RRTMG_QDIV_NR=2 gives 1 ulp.  Operands here are
+// O(1e-20..1e20) and never zero/inf/denormal.  NOT used where an integer selects a table ROW (specparm -> js):
+// those keep the correctly rounded `/`.  On the host (tests/emu) it is the plain division.
+#ifndef RRTMG_QDIV_NR
+#define RRTMG_QDIV_NR 1
+#endif
 RRTMG_HD double qdiv(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RRTMG_EXACT_DIV)
-  double r = __builtin_amdgcn_rcp(b);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);
+  double r = __builtin_amdgcn_rcp(b);                    // measured on gfx950: relative error <= 4.6e-8
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);    // one Newton step: <= 2.2e-15 (tools/micro/rcp_accuracy.hip)
+#if RRTMG_QDIV_NR >= 2
+  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);    // two: 1 ulp
+#endif
   return a * r;
 #else
   return a / b;
