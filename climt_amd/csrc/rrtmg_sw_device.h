@@ -504,9 +504,12 @@ RRTMG_HD double sw_dbt(const double *exp_tbl, double tau, double rmu0) {
 // reftra_sw for one layer, kmodts = 2 (rrtmg_sw_reftra.f90:148-316)
 // ZG0: the asymmetry parameter is exactly zero (clear sky without aerosol) -- the same arithmetic with the
 // terms that are then exactly 0 / 1 folded at compile time (identical results).  rmuz = 1/prmuz.
+// pdbt: the direct-beam transmittance exp(-zto1/prmuz) of the layer (rrtmg_sw_spcvrt.f90:562-574, sw_dbt) -- it is the
+// very table entry reftra looks up for its own exp(-zto1/prmuz) whenever zto1/prmuz <= 500 (reftra clamps there, the
+// direct beam does not), so it is handed out instead of being looked up a second time.
 template <bool ZG0 = false>
 RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double rmuz, double zto1, double zw, double &pref,
-                        double &prefd, double &ptra, double &ptrad) {
+                        double &prefd, double &ptra, double &ptrad, double &pdbt) {
   const double eps = 1.e-08, zwcrit = 0.9999995, od_lo = 0.06;
   double zgamma1, zgamma2, zgamma3, zwo;
   if constexpr (ZG0) {
@@ -527,10 +530,12 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     const double za = zgamma1 * prmuz;
     const double za1 = za - zgamma3;
     const double zgt = zgamma1 * zto1;
-    double ze1 = zto1 * rmuz;
+    const double zeu = zto1 * rmuz;
+    double ze1 = zeu;
     if (ze1 > 500.0) ze1 = 500.0;
     double ze2;
     if (ze1 <= od_lo) ze2 = 1.0 - ze1 + 0.5 * ze1 * ze1; else ze2 = sw_exp_lookup(exp_tbl, ze1);
+    pdbt = zeu > 500.0 ? sw_exp_lookup(exp_tbl, zeu) : ze2;
     pref = qdiv(zgt - za1 * (1.0 - ze2), 1.0 + zgt);   // same denominator below: one rcp on the device
     ptra = 1.0 - pref;
     prefd = qdiv(zgt, 1.0 + zgt);
@@ -555,11 +560,13 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
     const double zbeta = qdiv(zgamma1 - zrk, zrkg);
     double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
-    double ze2 = zto1 * rmuz; if (ze2 > 500.0) ze2 = 500.0;
+    const double zeu = zto1 * rmuz;
+    double ze2 = zeu; if (ze2 > 500.0) ze2 = 500.0;
     double zem1, zem2;
     if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
     const double zep1 = qrcp(zem1);
     if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
+    pdbt = zeu > 500.0 ? sw_exp_lookup(exp_tbl, zeu) : zem2;
     const double zep2 = qrcp(zem2);
     const double zdenr = zr4 * zep1 + zr5 * zem1;
     if (zdenr >= -eps && zdenr <= eps) {
@@ -863,15 +870,14 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c,
       ztauc = (1.0 - zwf) * ztauc;
       zomcc = qdiv(zomcc - zwf, 1.0 - zwf);
       zgcc = qdiv(zgcc - zf, 1.0 - zf);
-      sw_reftra<false>(exp_tbl, zgcc, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad);
+      sw_reftra<false>(exp_tbl, zgcc, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad, oc.dbt);
     } else {
       // no aerosol: taua = 0, omga = 1, asya = 0 -> zgcc = 0 and the delta scaling is the identity
       ztauc = taur[g] + taug[g];
       zomcc = qdiv(taur[g], ztauc);
       zgcc = 0.0;
-      sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad);
+      sw_reftra<true>(exp_tbl, 0.0, prmu0, rmu0, ztauc, zomcc, oc.ref, oc.refd, oc.tra, oc.trad, oc.dbt);
     }
-    oc.dbt = sw_dbt(exp_tbl, ztauc, rmu0);
     if (!CLD || !c.cloudy[g]) { consume(g, oc, oc); continue; }
     ot = oc;
     bool lcld;
@@ -885,9 +891,8 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c,
       double zomco = ztauc * zomcc + ptc * pomgc;
       const double zgco = qdiv(ptc * pomgc * pasyc + ztauc * zomcc * zgcc, zomco);
       zomco = qdiv(zomco, ztauo);
-      double refo, refdo, trao, trado;
-      sw_reftra<false>(exp_tbl, zgco, prmu0, rmu0, ztauo, zomco, refo, refdo, trao, trado);
-      const double dbto = sw_dbt(exp_tbl, ztauo, rmu0);
+      double refo, refdo, trao, trado, dbto;
+      sw_reftra<false>(exp_tbl, zgco, prmu0, rmu0, ztauo, zomco, refo, refdo, trao, trado, dbto);
       if (d.mcica) {
         ot.ref = refo; ot.refd = refdo; ot.tra = trao; ot.trad = trado; ot.dbt = dbto;
       } else {
