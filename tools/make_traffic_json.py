@@ -18,7 +18,7 @@ def get(mode, counter):
     out = {}
     for line in open(os.path.join(ROOT, "profiles", "%s_pmc_%s_%s.txt" % (rnd, mode, counter))):
         m = re.match(r"(.*?)\s+%s\s+dispatches\s+\d+\s+avg\s+(\S+)" % counter, line.strip())
-        if m and "solve_all" in m.group(1):
+        if m and "_solve_" in m.group(1):
             out[m.group(1).strip()] = float(m.group(2))
     return out
 
