@@ -59,12 +59,21 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 #ifndef RRTMG_LW_WAVES
 #define RRTMG_LW_WAVES 2
 #endif
+constexpr int kLwTileGroup = 32;
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
 // MR = true: non-McICA maximum/random overlap (rtrnmr).
 template <bool CLD, bool MR>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int q = blockIdx.x;
-  const int ctile = q % ntile, tile = tile0 + ctile, k = q / ntile;
+  // Launch order: tiles in groups of kLwTileGroup (a multiple of 8, so a tile stays on one XCD); within a group items
+  // heaviest first, tiles fastest; all items of a group before the next group -- the group's prep rows (4 tiles per
+  // XCD x 0.8 MB) stay L2-resident while its 38 items run (measured -3 %).
+  const int per = kLwTileGroup * T.nitem;
+  const int grp = q / per, r = q % per;
+  const int gt = ntile - grp * kLwTileGroup < kLwTileGroup ? ntile - grp * kLwTileGroup : kLwTileGroup;   // tiles in this group
+  const int ctile = grp * kLwTileGroup + r % gt, k = r / gt;
+  if (k >= T.nitem) return;     // padding blocks of a short last group
+  const int tile = tile0 + ctile;
   if ((d.tile_cld[tile] != 0) != CLD) return;
   const int slot = T.sched[k], item = T.item[slot];
   const int col = tile * 64 + threadIdx.x;
@@ -227,11 +236,12 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
+    const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwTileGroup * T.nitem;
     if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][0], s);
-    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
+    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
     if (clouds) {
-      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
-      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(nt * T.nitem), blk, 0, s, d, T, t0, nt);
+      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
+      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
     }
     if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][1], s);
     hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
