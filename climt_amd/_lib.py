@@ -153,10 +153,11 @@ class Context:
     def stream(self):
         return self.lib.rrtmg_hip_stream(self.h)
 
-    def kernel_ms(self, which):
-        """HIP-event duration (ms) of the last sw_solve_all (which='sw') / lw_solve_all ('lw') launch."""
+    def kernel_ms(self, which, cloudy=False):
+        """HIP-event duration (ms) of the last solve launch: which = 'sw' | 'lw'; cloudy selects the kernel that handles
+        the cloudy tiles (sw_solve_cloudy_kernel / lw_solve_all_kernel<true,..>) instead of the clear-sky one."""
         ms = C.c_double(0.0)
-        self._ck(self.lib.rrtmg_hip_kernel_ms(self.h, 0 if which == "sw" else 1, C.byref(ms)))
+        self._ck(self.lib.rrtmg_hip_kernel_ms(self.h, (0 if which == "sw" else 1) + (2 if cloudy else 0), C.byref(ms)))
         return ms.value
 
     def synchronize(self):

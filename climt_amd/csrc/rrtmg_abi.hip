@@ -31,7 +31,7 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   if (!ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   if (!ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_lw, hipStreamNonBlocking));
   if (!ctx->err_dev) RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
-  for (int w = 0; w < 2; ++w)
+  for (int w = 0; w < 4; ++w)
     for (int k = 0; k < 2; ++k)
       if (!ctx->ev[w][k]) RRTMG_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[w][k]));
   return RRTMG_OK;
@@ -90,7 +90,7 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
 const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 void *rrtmg_hip_stream(rrtmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms) {
-  if (!ctx || which < 0 || which > 1 || !ms || !ctx->ev_valid[which]) return RRTMG_ERR_ARG;
+  if (!ctx || which < 0 || which > 3 || !ms || !ctx->ev_valid[which]) return RRTMG_ERR_ARG;
   float f = 0.f;
   RRTMG_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
   *ms = (double)f;

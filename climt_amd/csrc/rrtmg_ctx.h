@@ -46,8 +46,10 @@ struct rrtmg_ctx {
   // grow-only device work buffers, by name
   std::map<std::string, rrtmg::DevBuf> bufs;
   int *err_dev = nullptr;
-  hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [sw|lw][start|stop] around the solve kernel
-  bool ev_valid[2] = {false, false};
+  // HIP events around the solve launches of the last column chunk: [0] sw clear-sky kernel, [1] lw clear-sky variant,
+  // [2] sw cloudy kernel, [3] lw cloudy variant; [start|stop]
+  hipEvent_t ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  bool ev_valid[4] = {false, false, false, false};
 
   int fail(int code, const char *fmt, ...) {
     char tmp[1024];

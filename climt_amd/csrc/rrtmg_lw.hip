@@ -237,16 +237,19 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwTileGroup * T.nitem;
-    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][0], s);
+    const bool last = t0 + ctile >= ntile;
+    if (last) (void)hipEventRecord(ctx->ev[1][0], s);
     hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
+    if (last) (void)hipEventRecord(ctx->ev[1][1], s);
     if (clouds) {
+      if (last) (void)hipEventRecord(ctx->ev[3][0], s);
       if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
+      if (last) (void)hipEventRecord(ctx->ev[3][1], s);
     }
-    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[1][1], s);
     hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
   }
-  ctx->ev_valid[1] = true;
+  ctx->ev_valid[1] = true; ctx->ev_valid[3] = clouds;
   hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -340,20 +340,25 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       }
     }
   }
-  // solve + spectral integration, one column chunk at a time (the events bracket the solve launches of the LAST chunk;
-  // with a single chunk -- up to chunk_tiles * 64 columns -- that is the whole solve)
+  // solve + spectral integration, one column chunk at a time (the event pairs bracket the two solve launches of the LAST
+  // chunk, one launch each; with a single chunk -- up to chunk_tiles * 64 columns -- that is the whole solve)
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
-    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[0][0], s);
+    const bool last = t0 + ctile >= ntile;
+    if (last) (void)hipEventRecord(ctx->ev[0][0], s);
     hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, t0, nt);
-    if (clouds) hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(nt * T.nitem[1]), blk, 0, s, d, T, t0, nt);
-    if (t0 + ctile >= ntile) (void)hipEventRecord(ctx->ev[0][1], s);
+    if (last) (void)hipEventRecord(ctx->ev[0][1], s);
+    if (clouds) {
+      if (last) (void)hipEventRecord(ctx->ev[2][0], s);
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(nt * T.nitem[1]), blk, 0, s, d, T, t0, nt);
+      if (last) (void)hipEventRecord(ctx->ev[2][1], s);
+    }
     hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
   }
-  ctx->ev_valid[0] = true;
+  ctx->ev_valid[0] = true; ctx->ev_valid[2] = clouds;
   hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -81,7 +81,9 @@ int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
  * next rrtmg_hip_synchronize / rrtmg_hip_set_deferred call instead.  Host-memory calls stay synchronous. */
 int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
 /* Duration (ms, HIP events recorded on the context's stream) of the dominant kernel of the last completed
- * call: which = 0 -> sw_solve_all_kernel, 1 -> lw_solve_all_kernel.  Returns RRTMG_ERR_ARG if never run. */
+ * call: which = 0 -> sw_solve_all_kernel<false> (clear-sky tiles), 1 -> lw_solve_all_kernel<false,..>, 2 -> sw_solve_cloudy_kernel,
+ * 3 -> lw_solve_all_kernel<true,..>; each bracket holds exactly one launch (of the last column chunk), so the value is what
+ * rocprofv3 reports for that kernel.  Returns RRTMG_ERR_ARG if that kernel was not launched by the last call. */
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
 
 /* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
