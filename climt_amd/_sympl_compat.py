@@ -50,6 +50,10 @@ except ImportError:
         ("seconds_per_day", "dimensionless"): 86400.0,
         ("heat_capacity_of_dry_air_at_constant_pressure", "J/kg/K"): 1004.64,
         ("stellar_irradiance", "W/m^2"): 1367.0,
+        ("heat_capacity_of_dry_air_at_constant_pressure", "J kg^-1 K^-1"): 1004.64,
+        ("gas_constant_of_dry_air", "J kg^-1 K^-1"): 287.0,
+        ("reference_air_pressure", "Pa"): 1.0132e5,
+        ("top_of_model_pressure", "Pa"): 20.0,
     }
     _constant_overrides = {}
 

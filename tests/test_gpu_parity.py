@@ -423,3 +423,45 @@ def test_components_on_gpu_reproduce_reference_caches():
     state, tend, diag = load_cache_case("TestRRTMGLongwave", "column")
     t, dg = lw(state)
     assert set(dg) == set(diag) and np.all(np.isfinite(t["air_temperature"].values))
+
+
+def test_model_script_setup_from_scratch_steps_to_reference_stepping_caches():
+    """state from get_grid/get_default_state (no fixture state), stepped 10 s by AdamsBashforth around
+    the drop-in components, against the reference's `*_stepping` caches (tests/test_components.py:123-160)."""
+    import datetime as dtm
+    import climt_amd
+    dt = dtm.timedelta(seconds=10)
+    for comp, cls, overwrite in ((climt_amd.RRTMGShortwave(), "TestRRTMGShortwave", None),
+                                 (climt_amd.SlabSurface(), "TestSlabSurface", "surface_material_density")):
+        want_state, tend, diag = load_cache_case(cls, "column")
+        state = climt_amd.get_default_state([comp], grid_state=climt_amd.get_grid(nx=None, ny=None, nz=30))
+        if overwrite:
+            state[overwrite].values[:] = 1029.0            # the reference test copies sea_water_density in (:542)
+        got_diag, new = climt_amd.AdamsBashforth(comp)(state, dt)
+        for k in diag:
+            g = np.transpose(got_diag[k].values, [got_diag[k].dims.index(x) for x in diag[k].dims])
+            assert maxdiff(g, diag[k].values) <= 1e-8, (cls, k)
+        for k, t in tend.items():
+            per_s = 1.0 / 86400.0 if "day" in t.attrs["units"] else 1.0
+            stepped = want_state[k].values + 10.0 * per_s * np.transpose(t.values, [t.dims.index(x) for x in want_state[k].dims])
+            assert maxdiff(new[k].values, stepped) <= 1e-11, (cls, k)
+        assert set(new) == set(state)
+
+
+def test_update_frequency_wrapper_skips_the_kernels_between_updates():
+    import datetime as dtm
+    import climt_amd
+    sw = climt_amd.RRTMGShortwave()
+    wrapped = climt_amd.UpdateFrequencyWrapper(sw, dtm.timedelta(hours=1))
+    state = climt_amd.get_default_state([sw], grid_state=climt_amd.get_grid(nx=4, ny=2, nz=20))
+    t0 = state["time"]
+    first = wrapped(state)
+    state["zenith_angle"].values[:] = 1.0
+    state["time"] = t0 + dtm.timedelta(minutes=30)
+    assert wrapped(state) is first                          # cached: the changed zenith angle is not seen yet
+    state["time"] = t0 + dtm.timedelta(hours=1)
+    later = wrapped(state)
+    assert later is not first
+    k = "downwelling_shortwave_flux_in_air"
+    ratio = later[1][k].values[-1] / first[1][k].values[-1]
+    np.testing.assert_allclose(ratio, np.cos(1.0), rtol=1e-12)   # TOA insolation scales with cos(zenith)

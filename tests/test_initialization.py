@@ -1,0 +1,179 @@
+"""get_grid / get_default_state / UpdateFrequencyWrapper against the reference's golden caches:
+each `*_stepping-1.cache` holds the complete default state its test built with get_default_state([component],
+grid_state=get_grid(...)) (tests/test_components.py:205-256,444-499), so every grid and default quantity is pinned --
+hybrid levels, pressures, Gaussian latitudes, the splined ozone profile, band-dimensioned defaults."""
+import datetime
+
+import numpy as np
+import pytest
+
+import climt_amd
+from climt_amd.initialization import get_default_state, get_grid, get_hybrid_sigma_pressure_levels, not_a_knot_spline
+
+from helpers import load_cache_case
+
+# (cache, component class, get_grid arguments, quantities the reference test overwrote after get_default_state)
+CASES = [
+    ("TestRRTMGLongwave", "column", climt_amd.RRTMGLongwave, dict(nz=30), ()),
+    ("TestRRTMGShortwave", "column", climt_amd.RRTMGShortwave, dict(nz=30), ()),
+    ("TestRRTMGLongwaveMCICA", "column", climt_amd.RRTMGLongwave, dict(nz=30), ()),
+    ("TestRRTMGLongwaveMCICA", "3d", climt_amd.RRTMGLongwave, dict(nx=10, ny=5),
+     ("cloud_area_fraction_in_atmosphere_layer", "mass_content_of_cloud_ice_in_atmosphere_layer")),
+    ("TestRRTMGShortwaveMCICA", "3d", climt_amd.RRTMGShortwave, dict(nx=3, ny=2, nz=15),
+     ("cloud_area_fraction_in_atmosphere_layer", "mass_content_of_cloud_ice_in_atmosphere_layer")),
+    ("TestSlabSurface", "column", climt_amd.SlabSurface, dict(nz=30), ("surface_material_density",)),
+    ("TestSlabSurface", "3d", climt_amd.SlabSurface, dict(nx=32, ny=16, nz=28), ("surface_material_density",)),
+]
+
+
+@pytest.mark.parametrize("cls,desc,component,grid_args,overwritten", CASES)
+def test_default_state_reproduces_reference_cache_states(cls, desc, component, grid_args, overwritten):
+    want, _, _ = load_cache_case(cls, desc)
+    # input_properties is a class attribute; instances need a GPU, the state generator does not
+    got = get_default_state([component], grid_state=get_grid(**grid_args))
+    assert set(want) == set(got)
+    for name, exp in want.items():
+        if name == "time":
+            assert got[name] == exp
+            continue
+        assert tuple(got[name].dims) == tuple(exp.dims), name
+        if name in overwritten:
+            assert got[name].shape == exp.shape
+            continue
+        g, e = np.asarray(got[name].values), np.asarray(exp.values)
+        if e.dtype.kind in "SU":
+            assert np.all(g.astype("U") == e.astype("U")), name
+        else:
+            np.testing.assert_allclose(g, e, rtol=1e-13, atol=0, err_msg=name)
+
+
+def test_hybrid_levels_properties_and_options():
+    for n, iso, sig in ((29, 0.25, 0.1), (61, 0.25, 0.1), (11, 0.3, 0.0)):
+        lev = get_hybrid_sigma_pressure_levels(n, 1.0e5, 20.0, iso, sig)
+        a = lev["atmosphere_hybrid_sigma_pressure_a_coordinate_on_interface_levels"].values
+        b = lev["atmosphere_hybrid_sigma_pressure_b_coordinate_on_interface_levels"].values
+        assert a.shape == b.shape == (n,)
+        assert b[0] == pytest.approx(1.0, abs=1e-14) and a[0] == pytest.approx(20.0) and a[-1] == 20.0
+        assert np.all(b[-int(iso * n):] == 0.0)                 # isobaric top
+        p = a + b * (1.0e5 - 20.0)
+        assert p[0] == pytest.approx(1.0e5) and np.all(np.diff(p) < 0)
+        assert np.all(np.diff(b) <= 1e-15) and np.all(b >= 0)
+    grid = get_grid(nx=4, ny=6, nz=10, latitude_grid="regular", x_name="x", y_name="y", n_ice_interface_levels=None)
+    assert grid["latitude"].dims == ("y", "x") and "height_on_ice_interface_levels" not in grid
+    np.testing.assert_allclose(grid["latitude"].values[:, 0], [-75, -45, -15, 15, 45, 75])
+    np.testing.assert_allclose(grid["longitude"].values[0], [0, 90, 180, 270])
+    assert grid["air_pressure"].shape == (10, 6, 4) and grid["air_pressure_on_interface_levels"].shape == (11, 6, 4)
+    pi = grid["air_pressure_on_interface_levels"].values
+    pm = grid["air_pressure"].values
+    assert np.all(pm < pi[:-1]) and np.all(pm > pi[1:])
+    with pytest.raises(ValueError):
+        get_grid(latitude_grid="icosahedral")
+
+
+def test_surface_pressure_and_interface_defaults():
+    grid = get_grid(nx=2, ny=3, nz=8, p_surf_in_Pa=9.5e4)
+    assert np.all(grid["surface_air_pressure"].values == 9.5e4)
+    np.testing.assert_allclose(grid["air_pressure_on_interface_levels"].values[0], 9.5e4)
+
+    class Needs:
+        input_properties = {"air_temperature_on_interface_levels": {"dims": ["interface_levels", "*"], "units": "degK"},
+                            "solar_cycle_fraction": {"dims": [], "units": "dimensionless"},
+                            "longwave_optical_depth_on_interface_levels": {"dims": ["interface_levels", "*"], "units": "dimensionless"},
+                            "snow_and_ice_temperature": {"dims": ["ice_interface_levels", "*"], "units": "degK"},
+                            "sea_surface_temperature": {"dims": ["*"], "units": "degK"}}
+
+    st = get_default_state([Needs], grid_state=grid)
+    assert st["air_temperature_on_interface_levels"].shape == (9, 3, 2) and np.all(st["air_temperature_on_interface_levels"].values == 290.0)
+    assert st["solar_cycle_fraction"].shape == () and st["solar_cycle_fraction"].dims == ()
+    tau = st["longwave_optical_depth_on_interface_levels"].values
+    assert abs(tau[0]).max() < 1e-15 and np.all(np.diff(tau, axis=0) > 0) and tau[-1].max() < 1.0
+    assert st["snow_and_ice_temperature"].dims == ("ice_interface_levels", "lat", "lon")
+    assert st["sea_surface_temperature"].shape == (3, 2)
+
+    class Unknown:
+        input_properties = {"no_such_quantity": {"dims": ["*"], "units": "m"}}
+
+    with pytest.raises(NotImplementedError, match="No initialization method"):
+        get_default_state([Unknown], grid_state=grid)
+
+
+def test_default_grid_when_none_is_given():
+    st = get_default_state([climt_amd.RRTMGLongwave, climt_amd.RRTMGShortwave])
+    assert st["air_temperature"].shape == (28, 1, 1) and st["height_on_ice_interface_levels"].shape == (30,)
+    assert st["aerosol_optical_depth_at_55_micron"].shape == (6, 28, 1, 1)
+    assert st["cloud_asymmetry_parameter"].shape == (28, 1, 1, 14) and st["surface_longwave_emissivity"].shape == (16, 1, 1)
+
+
+def test_spline_equals_scipy_cubic_spline():
+    interpolate = pytest.importorskip("scipy.interpolate")
+    rng = np.random.default_rng(5)
+    x = np.cumsum(rng.uniform(0.2, 2.0, 30))
+    y = rng.normal(size=30)
+    xn = np.concatenate((rng.uniform(x[0] - 2, x[-1] + 2, 400), x))
+    np.testing.assert_allclose(not_a_knot_spline(xn, x, y), interpolate.CubicSpline(x, y)(xn), rtol=0, atol=2e-12)
+    with pytest.raises(ValueError):
+        not_a_knot_spline([0.5], [0, 1, 2], [0, 1, 0])
+
+
+def test_update_frequency_wrapper_caches_between_updates():
+    class Counting:
+        tendency_properties = {"x": {}}
+
+        def __init__(self):
+            self.calls = 0
+
+        def __call__(self, state, **kw):
+            self.calls += 1
+            return {"x": self.calls}, {"kw": dict(kw)}
+
+    inner = Counting()
+    wrapped = climt_amd.UpdateFrequencyWrapper(inner, datetime.timedelta(minutes=30))
+    assert wrapped.tendency_properties == {"x": {}}          # attribute fall-through
+    t0 = datetime.datetime(2000, 1, 1)
+    seen = []
+    for minutes in (0, 10, 20, 30, 40, 59, 60, 61):
+        tend, _ = wrapped({"time": t0 + datetime.timedelta(minutes=minutes)})
+        seen.append(tend["x"])
+    assert seen == [1, 1, 1, 2, 2, 2, 3, 3] and inner.calls == 3
+    _, diag = wrapped({"time": t0 + datetime.timedelta(hours=5)}, timestep=datetime.timedelta(seconds=10))
+    assert diag["kw"] == {"timestep": datetime.timedelta(seconds=10)}
+    with pytest.raises(TypeError):
+        climt_amd.UpdateFrequencyWrapper(inner, 1800)
+
+
+def test_adams_bashforth_sums_tendencies_and_ramps_order():
+    from climt_amd._sympl_compat import DataArray
+
+    class Heating:
+        input_properties = {"air_temperature": {"dims": ["mid_levels", "*"], "units": "degK"}}
+
+        def __init__(self, rate, units, name, transposed=False):
+            self.rate, self.units, self.name, self.transposed = rate, units, name, transposed
+
+        def __call__(self, state):
+            t = state["air_temperature"]
+            vals, dims = np.full(t.shape, self.rate) * (1.0 + state["step"]), t.dims
+            if self.transposed:
+                vals, dims = vals.T, dims[::-1]
+            return {"air_temperature": DataArray(vals, dims=dims, attrs={"units": self.units})}, {self.name: state["step"]}
+
+    stepper = climt_amd.AdamsBashforth(Heating(86400.0, "degK day^-1", "a"), Heating(0.5, "K s^-1", "b", transposed=True))
+    assert set(stepper.input_properties) == {"air_temperature"}
+    dt = datetime.timedelta(seconds=10)
+    state = {"air_temperature": DataArray(np.full((3, 2), 290.0), dims=("mid_levels", "col"), attrs={"units": "degK"}),
+             "other": DataArray(np.arange(2.0), dims=("col",), attrs={"units": "m"}), "step": 0}
+    f = lambda n: 1.5 * (1.0 + n)                     # summed rate in K/s at step n
+    expect = 290.0
+    for n, weights in enumerate(((1.0,), (1.5, -0.5), (23 / 12, -16 / 12, 5 / 12), (23 / 12, -16 / 12, 5 / 12))):
+        state["step"] = n
+        diag, new = stepper(state, dt)
+        expect += 10.0 * sum(w * f(n - i) for i, w in enumerate(weights))
+        np.testing.assert_allclose(new["air_temperature"].values, expect, rtol=1e-14)
+        assert new["other"] is state["other"] and diag == {"a": n, "b": n}
+        assert new["air_temperature"].dims == ("mid_levels", "col") and new["air_temperature"].attrs["units"] == "degK"
+        assert state["air_temperature"].values[0, 0] != new["air_temperature"].values[0, 0]     # input state untouched
+        state = dict(new, step=n)
+    with pytest.raises(ValueError, match="constant"):
+        stepper(state, datetime.timedelta(seconds=20))
+    with pytest.raises(ValueError):
+        climt_amd.AdamsBashforth(Heating(1.0, "m s^-1", "a"))(state, dt)
