@@ -109,6 +109,14 @@ template <int G, int NG> struct KTab {
   const double *p;
 #ifdef RRTMG_ABL_UNIFORMK
   RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)(row & 1) * NG); }
+#elif defined(RRTMG_ABL_SCALARK) && defined(__HIP_DEVICE_COMPILE__)
+  RRTMG_HD V<G> operator[](int row) const {   // rows through the scalar cache
+    typedef const __attribute__((address_space(4))) double *cptr;
+    cptr q = (cptr)(p + (long)__builtin_amdgcn_readfirstlane(row) * NG);
+    V<G> r;
+    _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = q[i];
+    return r;
+  }
 #else
   RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)row * NG); }
 #endif

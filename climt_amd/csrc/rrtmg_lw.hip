@@ -49,43 +49,75 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
   if (col < d.ncol) lw_anymask_column(d, col);
 }
 
-// All 140 g-points in ONE launch.  Block = one wavefront = 64 columns of one tile x one work item (4 or 2
-// consecutive g-points of a band, LwTab::item).  The thread carries the item's g-points through both sweeps: the
-// layer state, the species mixtures (specparm/js/fs of the major, minor and Planck mixtures, adjusted columns),
-// the Planck functions and the cloud optics -- more than half of the per-g-point work of rtrnmc+taumol -- are
-// evaluated once per item, and every table row is one 16/32-byte load.  The item's band-weighted radiances are
-// summed in registers: part[item][k][level][column].  Launch order: items heaviest first (LwTab::sched), tiles
-// fastest (a tile count that is a multiple of 8 keeps a tile on one XCD).  Speed only, never correctness.
+// All 140 g-points in ONE launch.  Wavefront = 64 columns of one tile x one work item (4 or 2 consecutive g-points
+// of a band, LwTab::item).  The thread carries the item's g-points through both sweeps: the layer state, the species
+// mixtures (specparm/js/fs of the major, minor and Planck mixtures, adjusted columns), the Planck functions and the
+// cloud optics -- more than half of the per-g-point work of rtrnmc+taumol -- are evaluated once per item.  The item's
+// band-weighted radiances are summed in registers: part[item][k][level][column].
+// Workgroup = kLwWgWaves wavefronts = the same item for kLwWgWaves consecutive tiles, sharing ONE copy of the item's
+// k-distribution slice in LDS: columns ig0..ig0+G-1 of the band's table slab, [nrows][G], <= 66 KB, two workgroups per
+// CU.  Every absorption-coefficient / Planck-fraction row a lane needs is then a 16/32-byte LDS read at a per-lane
+// row (bank conflicts only) instead of a per-lane gather through the vector L1, whose return path (64 B/clk/CU) the
+// ~30 row gathers per layer saturated: with the rows through the scalar cache (RRTMG_ABL_SCALARK) the kernel ran 23 %
+// faster, which bounded what staging could win.
+// Launch order: tile groups of kLwTileGroup, within a group items heaviest first (LwTab::sched), tile blocks fastest
+// -- the group's prep rows stay L2-resident while its items run.  Speed only, never correctness.
 #ifndef RRTMG_LW_WAVES
 #define RRTMG_LW_WAVES 2
 #endif
+#ifndef RRTMG_LW_WGWAVES
+#define RRTMG_LW_WGWAVES 4
+#endif
+constexpr int kLwWgWaves = RRTMG_LW_WGWAVES;
 constexpr int kLwTileGroup = 32;
+constexpr int kLwGroupBlocks = kLwTileGroup / kLwWgWaves;
+static_assert(kLwTileGroup % kLwWgWaves == 0, "tile group must be a whole number of workgroups");
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
 // MR = true: non-McICA maximum/random overlap (rtrnmr).
 template <bool CLD, bool MR>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
+__global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int q = blockIdx.x;
-  // Launch order: tiles in groups of kLwTileGroup (a multiple of 8, so a tile stays on one XCD); within a group items
-  // heaviest first, tiles fastest; all items of a group before the next group -- the group's prep rows (4 tiles per
-  // XCD x 0.8 MB) stay L2-resident while its 38 items run (measured -3 %).
-  const int per = kLwTileGroup * T.nitem;
+  const int per = kLwGroupBlocks * T.nitem;
   const int grp = q / per, r = q % per;
-  const int gt = ntile - grp * kLwTileGroup < kLwTileGroup ? ntile - grp * kLwTileGroup : kLwTileGroup;   // tiles in this group
-  const int ctile = grp * kLwTileGroup + r % gt, k = r / gt;
-  if (k >= T.nitem) return;     // padding blocks of a short last group
-  const int tile = tile0 + ctile;
-  if ((d.tile_cld[tile] != 0) != CLD) return;
+  const int k = r / kLwGroupBlocks;
+  const int ctile0 = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;   // first tile (within the chunk) of this workgroup
+  {
+    // workgroup-uniform early exit before the slice is staged: none of this group's tiles is ours
+    bool mine = false;
+    for (int w = 0; w < kLwWgWaves; ++w)
+      if (ctile0 + w < ntile && (d.tile_cld[tile0 + ctile0 + w] != 0) == CLD) mine = true;
+    if (!mine) return;
+  }
   const int slot = T.sched[k], item = T.item[slot];
-  const int col = tile * 64 + threadIdx.x;
+  const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
+#ifdef RRTMG_LW_NOLDS
+  constexpr bool kLdsK = false;
+  const double *sh_k = nullptr;
+#else
+  constexpr bool kLdsK = true;
+  __shared__ double sh_k[kLwSlabMaxRows * 4];
+  {
+    const LwBandTab &B = T.b[item & 0xff];
+    const double *src = T.t + B.slab + ig0;
+    const int ng = B.ng, sh = g == 4 ? 2 : 1, n = B.nrows << sh;
+    for (int i = threadIdx.x; i < n; i += 64 * kLwWgWaves) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
+  }
+  __syncthreads();
+#endif
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ctile = ctile0 + wave, tile = tile0 + ctile;
+  if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
+  const int lane = threadIdx.x & 63;
+  const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + threadIdx.x * ((item >> 16) & 0xf);
+  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + lane * g;
   LwPartSink sink = lw_part_sink(d, slot, col);
-  lw_solve_item<CLD, MR>(d, T, item, col, scr, 64, sink);
+  lw_solve_item<CLD, MR, kLdsK>(d, T, item, col, scr, 64, sink, sh_k);
 }
 
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T, int tile0) {
   const int col = (tile0 + blockIdx.x) * 64 + threadIdx.x;
-  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem);
+  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem, d.tile_cld[tile0 + blockIdx.x] != 0);
 }
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -236,15 +268,16 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
-    const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwTileGroup * T.nitem;
+    const dim3 lwwg(64 * kLwWgWaves);
+    const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const bool last = t0 + ctile >= ntile;
     if (last) (void)hipEventRecord(ctx->ev[1][0], s);
-    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
+    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
     if (last) (void)hipEventRecord(ctx->ev[1][1], s);
     if (clouds) {
       if (last) (void)hipEventRecord(ctx->ev[3][0], s);
-      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
-      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), blk, 0, s, d, T, t0, nt);
+      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       if (last) (void)hipEventRecord(ctx->ev[3][1], s);
     }
     hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);

@@ -25,11 +25,17 @@ constexpr int kLwNGpt = 140;
 struct LwBandTab {
   int ng, gs;
   int nfraca, nfracb;      // Planck-fraction mixtures (1, 9 / 1, 5)
-  long absa, absb, self, forr, fraca, fracb;   // absa/absb/self/forr: g-point-fastest copies [row][ng]
-  long ma[3];              // lower-atmosphere minor-gas tables, g-point-fastest [19 * nm][ng]
-  long mb[2];              // upper-atmosphere minor-gas tables, g-point-fastest
-  long x[2];               // cross-section tables (ccl4 | cfc11adj, cfc12 | cfc12, cfc22adj)
+  // Every per-g-point table of the band lives in ONE g-point-fastest slab [nrows][ng] at T.t + slab (built at init);
+  // r_* = first row of each table in it.  A work item's slice of the slab -- columns ig0 .. ig0+G-1, [nrows][G] --
+  // is what the solve kernel stages in LDS, rows unchanged.
+  long slab;
+  int nrows;
+  int r_absa, r_absb, r_self, r_forr, r_fraca, r_fracb;
+  int r_ma[3];             // lower-atmosphere minor-gas tables [19 * nm] rows
+  int r_mb[2];             // upper-atmosphere minor-gas tables
+  int r_x[2];              // cross-section rows (ccl4 | cfc11adj, cfc12 | cfc12, cfc22adj)
 };
+constexpr int kLwSlabMaxRows = 2056;   // band 3: 585 + 1175 + 10 + 4 + 171 + 95 + 9 + 5 rows (checked at init)
 
 // work items of the solve kernel: see SwTab (packed band | ig0 << 8 | G << 16 | first g-point << 20)
 constexpr int kLwMaxItem = 72;
@@ -631,16 +637,21 @@ constexpr int kLwNg[16] = {10, 12, 16, 14, 16, 8, 12, 8, 12, 6, 8, 8, 4, 2, 2, 2
 enum { CR_12 = 0, CR_32, CR_13, CR_16, CR_14, CR_42, CR_N };
 
 // gas optical depths and Planck fractions of the G g-points ig0 .. ig0+G-1 of band BAND (1..16) in one layer
-template <int BAND, int G>
-RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V<G> &fracs) {
+// LDSK = true: kb -> the item's slice of the band slab, [nrows][G] (the workgroup's LDS copy); LDSK = false: kb is
+// ignored and the slab is read in place, [nrows][ng], through the vector L1.
+template <int BAND, int G, bool LDSK = false>
+RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V<G> &fracs, const double *kb = nullptr) {
   const LwBandTab &B = T.b[BAND - 1];
   const double *t = T.t;
   constexpr int NG = kLwNg[BAND - 1];
-  // g-point-fastest table views ([row][ng], rows as in the reference's first dimensions)
-  const KTab<G, NG> absa{t + B.absa + ig0}, absb{t + B.absb + ig0}, selfref{t + B.self + ig0}, forref{t + B.forr + ig0};
-  const KTab<G, NG> ma0{t + B.ma[0] + ig0}, ma1{t + B.ma[1] + ig0}, ma2{t + B.ma[2] + ig0}, mb0{t + B.mb[0] + ig0}, mb1{t + B.mb[1] + ig0};
-  const KTab<G, NG> fraca{t + B.fraca + ig0}, fracb{t + B.fracb + ig0};
-  auto row = [&](long base) { return vload<G>(t + base + ig0); };   // a [ng] table
+  constexpr int ST = LDSK ? G : NG;
+  if (!LDSK) kb = t + B.slab + ig0;
+  // g-point-fastest table views ([row][ST], rows as in the reference's first dimensions)
+  auto view = [&](int r) { return KTab<G, ST>{kb + (long)r * ST}; };
+  const KTab<G, ST> absa = view(B.r_absa), absb = view(B.r_absb), selfref = view(B.r_self), forref = view(B.r_forr);
+  const KTab<G, ST> ma0 = view(B.r_ma[0]), ma1 = view(B.r_ma[1]), ma2 = view(B.r_ma[2]), mb0 = view(B.r_mb[0]), mb1 = view(B.r_mb[1]);
+  const KTab<G, ST> fraca = view(B.r_fraca), fracb = view(B.r_fracb);
+  auto row = [&](int r) { return vload<G>(kb + (long)r * ST); };   // a one-row ([ng]) table
   V<G> taug = vsplat<G>(0.0);
   const int i0s = ((s.jp - 1) * 5 + (s.jt - 1)), i1s = (s.jp * 5 + (s.jt1 - 1));         // lower, nspa = 1
   // band 16 has a kb table but nspb(16) = 0 in lwdatinit, so the reference's index
@@ -702,14 +713,14 @@ RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V
       if constexpr (BAND == 5) {
         const LwSpec sm = lw_spec(s.colh2o, chirat(CR_12, 7), s.colco2, 8.0);
         const V<G> abso3 = lw_minor2(ma0, 9, sm.js, sm.fs, s);
-        taug = taug + abso3 * s.colo3 + s.wx1 * row(B.x[0]);
+        taug = taug + abso3 * s.colo3 + s.wx1 * row(B.r_x[0]);
       }
       fracs = lw_frac2(fraca, pl);
     } else {
       const LwSpec sp = lw_spec(s.colo3, chirat(CR_32, s.jp), s.colco2, 4.0), sp1 = lw_spec(s.colo3, chirat(CR_32, s.jp + 1), s.colco2, 4.0);
       const LwSpec pl = lw_spec(s.colo3, chirat(CR_32, BAND == 4 ? 13 : 43), s.colco2, 4.0);
       taug = lw_major_upper(absb, u0s * 5 + sp.js - 1, sp, s.fac00, s.fac10) + lw_major_upper(absb, u1s * 5 + sp1.js - 1, sp1, s.fac01, s.fac11);
-      if constexpr (BAND == 5) taug = taug + s.wx1 * row(B.x[0]);
+      if constexpr (BAND == 5) taug = taug + s.wx1 * row(B.r_x[0]);
       fracs = lw_frac2(fracb, pl);
       if constexpr (BAND == 4) {
         // empirical stratospheric scalings, default-real literals (rrtmg_lw_taumol.f90:1009-1015)
@@ -723,9 +734,9 @@ RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V
       const double adjcolco2 = lw_adjcol(s.colco2, s.coldry, lw_chi(T, 2, s.jp + 1), 1.e20, 3.0, 2.0, 0.77, lw_chi(T, 2, s.jp + 1));
       const V<G> absco2 = lw_minor1(ma0, s);
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 +
-             s.wx2 * row(B.x[0]) + s.wx3 * row(B.x[1]);
+             s.wx2 * row(B.r_x[0]) + s.wx3 * row(B.r_x[1]);
     } else {
-      taug = 0.0 + s.wx2 * row(B.x[0]) + s.wx3 * row(B.x[1]);
+      taug = 0.0 + s.wx2 * row(B.r_x[0]) + s.wx3 * row(B.r_x[1]);
     }
     fracs = fraca[0];
   } else if constexpr (BAND == 7) {
@@ -752,11 +763,11 @@ RRTMG_HD V<G> lw_taug(const LwTab &T, const LwLayerIn &s, bool lower, int ig0, V
     if (lower) {
       const V<G> absco2 = lw_minor1(ma0, s), abso3 = lw_minor1(ma1, s), absn2o = lw_minor1(ma2, s);
       taug = s.colh2o * lw_m4(absa, i0s, i1s, s) + lw_tauself(selfref, s) + lw_taufor(forref, s) + adjcolco2 * absco2 + s.colo3 * abso3 +
-             s.coln2o * absn2o + s.wx3 * row(B.x[0]) + s.wx4 * row(B.x[1]);
+             s.coln2o * absn2o + s.wx3 * row(B.r_x[0]) + s.wx4 * row(B.r_x[1]);
       fracs = fraca[0];
     } else {
       const V<G> absco2 = lw_minor1(mb0, s), absn2o = lw_minor1(mb1, s);
-      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2 + s.coln2o * absn2o + s.wx3 * row(B.x[0]) + s.wx4 * row(B.x[1]);
+      taug = s.colo3 * lw_m4(absb, u0s, u1s, s) + adjcolco2 * absco2 + s.coln2o * absn2o + s.wx3 * row(B.r_x[0]) + s.wx4 * row(B.r_x[1]);
       fracs = fracb[0];
     }
   } else if constexpr (BAND == 9) {
@@ -887,6 +898,13 @@ struct LwPartSink {
     p[(long)lev * N] = ru; p[2 * st + (long)lev * N] = rcu;
     if (idrv) { p[4 * st + (long)lev * N] = du; p[5 * st + (long)lev * N] = dcu; }
   }
+  // cloud-free column (CLD = false variant): the clear-sky radiances ARE the total ones, so only the total planes
+  // are written and lw_flux_level(cld = false) reads them for both outputs (half the partial-plane traffic)
+  RRTMG_HD void dn_clear(int lev, double rd) { p[st + (long)lev * N] = rd; }
+  RRTMG_HD void up_clear(int lev, double ru, double du) {
+    p[(long)lev * N] = ru;
+    if (idrv) p[4 * st + (long)lev * N] = du;
+  }
 };
 RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   LwPartSink s;
@@ -908,8 +926,8 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
 // CLD = false: the caller guarantees a cloud-free column (the cloud code is compiled out).
 // MR = true (non-McICA icld >= 2): rtrnmr, maximum/random overlap of the cloudy layers (rrtmg_lw_rtrnmr.f90:454-700)
 // with the column's overlap factors from lw_mr_column; MR = false: rtrn / rtrnmc.
-template <int BAND, int G, bool CLD, bool MR, class Sink>
-RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, double *scr, long stride, Sink &sink) {
+template <int BAND, int G, bool CLD, bool MR, bool LDSK, class Sink>
+RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   const int L = d.nlay, N = d.ncol;
   const int ib = BAND - 1;
   const int iw0 = T.b[ib].gs + ig0;
@@ -961,7 +979,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   int iclddn[G];
 #pragma unroll
   for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; cldrad[g] = 0.0; clrrad[g] = 0.0; radmr[g] = 0.0; }
-  sink.dn(L, 0.0, 0.0);
+  if constexpr (CLD) sink.dn(L, 0.0, 0.0); else sink.dn_clear(L, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
   for (int lev = L; lev >= 1; --lev) {
     const int l = lev - 1;
@@ -972,7 +990,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 #ifdef RRTMG_ABL_NOTAUG
     plfrac = vsplat<G>(0.1); const V<G> taug = vsplat<G>(s.colh2o * 1.0e-3 + s.fac00);
 #else
-    const V<G> taug = lw_taug<BAND, G>(T, s, lev <= laytrop, ig0, plfrac);
+    const V<G> taug = lw_taug<BAND, G, LDSK>(T, s, lev <= laytrop, ig0, plfrac, kb);
 #endif
     const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
     const double tz_dn = d.tlev[i];
@@ -1119,7 +1137,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     vstore<G>(SP(LF_ATRANS, l), v_atrans);
     vstore<G>(SP(LF_BBUGAS, l), v_bbugas);
     if (icldlyr) { vstore<G>(SP(LF_ATOT, l), v_atot); vstore<G>(SP(LF_BBUTOT, l), v_bbutot); }
-    sink.dn(lev - 1, srd, srcd);
+    if constexpr (CLD) sink.dn(lev - 1, srd, srcd); else sink.dn_clear(lev - 1, srd);
   }
 
   // ---- surface ------------------------------------------------------------------------------
@@ -1142,7 +1160,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       }
       s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
     }
-    sink.up(0, s0, s1, s2, s3);
+    if constexpr (CLD) sink.up(0, s0, s1, s2, s3); else sink.up_clear(0, s0, s2);
   }
 
   // ---- upward sweep: kU layers at a time, their scratch rows are loaded before the first is used ----------
@@ -1229,40 +1247,41 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         }
         s0 = s0 + W(radlu[g]); s1 = s1 + W(radclru[g]); s2 = s2 + W(d_radlu_dt[g]); s3 = s3 + W(d_radclru_dt[g]);
       }
-      sink.up(lev, s0, s1, s2, s3);
+      if constexpr (CLD) sink.up(lev, s0, s1, s2, s3); else sink.up_clear(lev, s0, s2);
     }
   }
 }
 
 // Dispatch of one work item (packed, see LwTab) for one column: band switch + G in {4, 2}.
-template <int BAND, bool CLD, bool MR, class Sink>
-RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
+template <int BAND, bool CLD, bool MR, bool LDSK, class Sink>
+RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = kLwNg[BAND - 1];
   if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
-    if (g == 4) { lw_solve_thread<BAND, 4, CLD, MR>(d, T, col, ig0, scr, stride, sink); return; }
+    if (g == 4) { lw_solve_thread<BAND, 4, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD, MR>(d, T, col, ig0, scr, stride, sink);
+  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb);
 }
-template <bool CLD, bool MR, class Sink>
-RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, double *scr, long stride, Sink &sink) {
+// LDSK / kb: see lw_taug (kb = the workgroup's LDS slice of the item's band slab, or nullptr with LDSK = false)
+template <bool CLD, bool MR, bool LDSK = false, class Sink>
+RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, double *scr, long stride, Sink &sink, const double *kb = nullptr) {
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
   switch ((item & 0xff) + 1) {
-    case 1: lw_solve_band<1, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 2: lw_solve_band<2, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 3: lw_solve_band<3, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 4: lw_solve_band<4, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 5: lw_solve_band<5, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 6: lw_solve_band<6, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 7: lw_solve_band<7, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 8: lw_solve_band<8, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 9: lw_solve_band<9, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 10: lw_solve_band<10, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 11: lw_solve_band<11, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 12: lw_solve_band<12, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 13: lw_solve_band<13, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 14: lw_solve_band<14, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    case 15: lw_solve_band<15, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
-    default: lw_solve_band<16, CLD, MR>(d, T, g, col, ig0, scr, stride, sink); break;
+    case 1: lw_solve_band<1, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 2: lw_solve_band<2, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 3: lw_solve_band<3, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 4: lw_solve_band<4, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 5: lw_solve_band<5, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 6: lw_solve_band<6, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 7: lw_solve_band<7, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 8: lw_solve_band<8, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 9: lw_solve_band<9, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 10: lw_solve_band<10, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 11: lw_solve_band<11, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 12: lw_solve_band<12, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 13: lw_solve_band<13, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 14: lw_solve_band<14, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    case 15: lw_solve_band<15, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
+    default: lw_solve_band<16, CLD, MR, LDSK>(d, T, g, col, ig0, scr, stride, sink, kb); break;
   }
 }
 
@@ -1270,7 +1289,7 @@ RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, d
 // one thread per (column, interface level)
 // nparts = number of work items (T.nitem); each partial is the sum over its item's g-points and already carries
 // wtdiff*delwave(band)
-RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts) {
+RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts, bool cld) {
   (void)T;
   const int L = d.nlay, N = d.ncol;
   const int nk = d.idrv ? 6 : 4;
@@ -1278,9 +1297,14 @@ RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, in
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
   for (int iw = 0; iw < nparts; ++iw) {
     const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * d.pcols + (col - d.col0);
-    t0 = t0 + p[0]; t1 = t1 + p[st]; t2 = t2 + p[2 * st]; t3 = t3 + p[3 * st];
-    if (d.idrv) { t4 = t4 + p[4 * st]; t5 = t5 + p[5 * st]; }
+    t0 = t0 + p[0]; t1 = t1 + p[st];
+    if (d.idrv) t4 = t4 + p[4 * st];
+    if (cld) {
+      t2 = t2 + p[2 * st]; t3 = t3 + p[3 * st];
+      if (d.idrv) t5 = t5 + p[5 * st];
+    }
   }
+  if (!cld) { t2 = t0; t3 = t1; t5 = t4; }   // the clear-sky variant wrote the total planes only (LwPartSink::dn_clear)
   const long o = (long)lev * N + col;
   d.uflx[o] = t0 * d.fluxfac; d.dflx[o] = t1 * d.fluxfac; d.uflxc[o] = t2 * d.fluxfac; d.dflxc[o] = t3 * d.fluxfac;
   if (d.idrv) { d.duflx_dt[o] = t4 * d.fluxfac; d.duflxc_dt[o] = t5 * d.fluxfac; }

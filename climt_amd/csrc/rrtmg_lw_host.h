@@ -33,24 +33,32 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
     B.ng = (*ngc)[b];
     B.gs = b == 0 ? 0 : (*ngs)[b - 1];
     if (B.ng != kLwNg[b]) { err = "reduced g-point count of band " + std::to_string(b + 1) + " differs from the compiled-in one"; return false; }
-    // g-point-fastest copies ([row][ng]) of the per-g-point tables ([ng][row]) for the vector loads of the kernel
-    auto gfast = [&](const std::string &n, bool required) -> long {
+    // ONE g-point-fastest slab [nrows][ng] per band holding all its per-g-point tables (the blob stores them [ng][row],
+    // the Planck-fraction and cross-section tables [row][ng] already); LwBandTab::r_* = first row of each table
+    std::vector<double> slab;
+    auto append = [&](const std::string &n, bool required, bool transposed) -> int {
       auto it = ts.reg.find(p + n);
       if (it == ts.reg.end()) { if (required) err = "reduced table '" + p + n + "' missing"; return 0; }
       const long o = it->second.off, rows = it->second.n / B.ng;
-      std::vector<double> tr((size_t)it->second.n);
+      const int r0 = (int)(slab.size() / B.ng);
+      slab.resize(slab.size() + (size_t)rows * B.ng);
       for (int ig = 0; ig < B.ng; ++ig)
-        for (long r = 0; r < rows; ++r) tr[(size_t)r * B.ng + ig] = ts.flat[(size_t)o + (size_t)ig * rows + r];
-      return ts.add(p + n + "_g", tr.data(), (long)tr.size(), {(uint32_t)rows, (uint32_t)B.ng});
+        for (long r = 0; r < rows; ++r)
+          slab[(size_t)(r0 + r) * B.ng + ig] = ts.flat[(size_t)o + (transposed ? (size_t)ig * rows + r : (size_t)r * B.ng + ig)];
+      return r0;
     };
-    B.absa = gfast("absa", true); B.absb = gfast("absb", false);
-    B.self = gfast("selfref", true); B.forr = gfast("forref", true);
-    B.fraca = off(p + "fracrefa", true); B.fracb = off(p + "fracrefb", false);
+    B.r_absa = append("absa", true, true); B.r_absb = append("absb", false, true);
+    B.r_self = append("selfref", true, true); B.r_forr = append("forref", true, true);
+    B.r_fraca = append("fracrefa", true, false); B.r_fracb = append("fracrefb", false, false);
     { auto it = ts.reg.find(p + "fracrefa"); B.nfraca = it != ts.reg.end() && it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
     { auto it = ts.reg.find(p + "fracrefb"); B.nfracb = it != ts.reg.end() && it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
-    for (int k = 0; k < 3; ++k) B.ma[k] = MA[b][k] ? gfast(MA[b][k], true) : 0;
-    for (int k = 0; k < 2; ++k) B.mb[k] = MB[b][k] ? gfast(MB[b][k], true) : 0;
-    for (int k = 0; k < 2; ++k) B.x[k] = X[b][k] ? off(p + X[b][k], true) : 0;
+    for (int k = 0; k < 3; ++k) B.r_ma[k] = MA[b][k] ? append(MA[b][k], true, true) : 0;
+    for (int k = 0; k < 2; ++k) B.r_mb[k] = MB[b][k] ? append(MB[b][k], true, true) : 0;
+    for (int k = 0; k < 2; ++k) B.r_x[k] = X[b][k] ? append(X[b][k], true, false) : 0;
+    if (!err.empty()) return false;
+    B.nrows = (int)(slab.size() / B.ng);
+    if (B.nrows > kLwSlabMaxRows) { err = "band " + std::to_string(b + 1) + " table slab has more rows than kLwSlabMaxRows"; return false; }
+    B.slab = ts.add(p + "slab_g", slab.data(), (long)slab.size(), {(uint32_t)B.nrows, (uint32_t)B.ng});
     if (!err.empty()) return false;
   }
   T.preflog = off("lw/ref/preflog", true); T.tref = off("lw/ref/tref", true); T.chi_mls = off("lw/ref/chi_mls", true);

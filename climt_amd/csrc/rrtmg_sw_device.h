@@ -802,6 +802,12 @@ struct SwPartSink {
     const long o = pair * slot_stride + (long)lev * N;
     pfu[o] = fu; pfd[o] = fd; pcu[o] = cu; pcd[o] = cd;
   }
+  // cloud-free column (CLD = false variant): clear-sky == total, only the total planes are written and
+  // sw_flux_level(pairs = false) reads them for both outputs
+  RRTMG_HD void emit_clear(int lev, double fu, double fd) {
+    const long o = (long)lev * N;
+    pfu[o] = fu; pfd[o] = fd;
+  }
 };
 RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int slot, int col) {
   const long N = d.pcols, L1 = d.nlay + 1;
@@ -1027,9 +1033,9 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
       for (int h = 0; h < G / 2; ++h) sink.emit(h, lev, sfu[h], sfd[h], scu[h], scd[h]);   // one slot per pair
     } else if constexpr (G == 4) {
-      sink.emit(0, lev, sfu[0] + sfu[1], sfd[0] + sfd[1], scu[0] + scu[1], scd[0] + scd[1]);   // one slot per chunk
+      sink.emit_clear(lev, sfu[0] + sfu[1], sfd[0] + sfd[1]);   // one slot per chunk
     } else {
-      sink.emit(0, lev, sfu[0], sfd[0], scu[0], scd[0]);
+      sink.emit_clear(lev, sfu[0], sfd[0]);
     }
     if (lev > 0) {
       const int l = lev - 1;
@@ -1100,10 +1106,13 @@ RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bo
     const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
     if (pairs && T.chunk_npair[c] == 2) {
       fu = fu + (p[0] + p[slot]); fd = fd + (p[st] + p[slot + st]); cu = cu + (p[2 * st] + p[slot + 2 * st]); cd = cd + (p[3 * st] + p[slot + 3 * st]);
-    } else {
+    } else if (pairs) {
       fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
+    } else {
+      fu = fu + p[0]; fd = fd + p[st];
     }
   }
+  if (!pairs) { cu = fu; cd = fd; }   // the clear-sky variant wrote the total planes only (SwPartSink::emit_clear)
   const long o = (long)lev * N + col;
   d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
 }

@@ -15,14 +15,18 @@ namespace rrtmg {
 void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
 }
 
+// the clear-sky variant for cloud-free columns, as the device picks it per tile
+static bool emu_lw_cloudy(const LwDev &d, int col) {
+  bool cld = false;
+  if (d.icld >= 1 && d.cldfr) for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(size_t)l * d.ncol + col] > 0.0;
+  return cld;
+}
 static void emu_lw_solve(const LwDev &d, const LwTab &T) {
   std::vector<double> scr((size_t)LF_N * d.nlay * 4);
   for (int slot = 0; slot < T.nitem; ++slot)
     for (int col = 0; col < d.ncol; ++col) {
       LwPartSink sink = lw_part_sink(d, slot, col);
-      // the clear-sky variant for cloud-free columns, as the device picks it per tile
-      bool cld = false;
-      if (d.icld >= 1 && d.cldfr) for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(size_t)l * d.ncol + col] > 0.0;
+      const bool cld = emu_lw_cloudy(d, col);
       if (cld && !d.mcica && d.icld >= 2) lw_solve_item<true, true>(d, T, T.item[slot], col, scr.data(), 1, sink);
       else if (cld) lw_solve_item<true, false>(d, T, T.item[slot], col, scr.data(), 1, sink);
       else lw_solve_item<false, false>(d, T, T.item[slot], col, scr.data(), 1, sink);
@@ -94,7 +98,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
     }
   }
   emu_lw_solve(d, T);
-  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev, T.nitem);
+  for (int lev = 0; lev <= L; ++lev) for (int c = 0; c < N; ++c) lw_flux_level(d, T, c, lev, T.nitem, emu_lw_cloudy(d, c));
   for (int l = 0; l < L; ++l) for (int c = 0; c < N; ++c) lw_heat_layer(d, T, c, l);
   if (errflag) return fail(errflag, "device-side error flag " + std::to_string(errflag));
   return 0;
