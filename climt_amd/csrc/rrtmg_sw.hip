@@ -63,13 +63,16 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
   }
 }
 
-// All 112 g-points in ONE launch.  Wavefront = 64 columns of one tile x one work item (2 consecutive g-points
+// All 112 g-points in ONE launch.  Wavefront = 64 columns of one tile x one work item (4 or 2 consecutive g-points
 // of a band, SwTab::item): the thread carries the item's g-points through both sweeps, so the layer state, species
-// mixtures and interpolation weights are evaluated once per item and every table row is one 16-byte load; the
-// item's weighted fluxes are summed in registers: part[item][k][level][column].
-// Workgroup = 8 wavefronts = the same item for 8 consecutive tiles (equal run times), sharing ONE copy of the
-// 10001-entry transmittance table in LDS (80 KB, two workgroups per CU): its lookups are per-lane random and
-// cost a tag lookup per lane in the vector L1, but only bank conflicts in LDS.
+// mixtures and interpolation weights are evaluated once per item; the item's weighted fluxes are summed in
+// registers: part[item][k][level][column].
+// Workgroup = 16 wavefronts = the same item for 16 consecutive tiles (equal run times), one workgroup per CU,
+// sharing in LDS (a) ONE copy of the 10001-entry transmittance table (80 KB): its lookups are per-lane random and
+// cost a tag lookup per lane in the vector L1, but only bank conflicts in LDS; (b) the item's k-distribution slice,
+// columns ig0..ig0+G-1 of the band's table slab, [nrows][G] (<= 58 KB): every absorption-coefficient row a lane
+// needs is a 32-byte LDS read instead of a per-lane gather through the vector L1's 64 B/clk return path
+// (measured: -6 % kernel time; with the rows through the scalar cache, RRTMG_ABL_SCALARK, -10 % was the bound).
 // Launch order: items heaviest first (SwTab::sched), tile groups fastest.  Speed only, never correctness.
 #ifndef RRTMG_SW_WAVES
 #define RRTMG_SW_WAVES 4
@@ -78,11 +81,22 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 constexpr int kSwWgWaves = 1;
 #else
 #ifndef RRTMG_SW_WGWAVES
-#define RRTMG_SW_WGWAVES 8
+#define RRTMG_SW_WGWAVES 16
 #endif
 constexpr int kSwWgWaves = RRTMG_SW_WGWAVES;
 #endif
 constexpr int kExpTblN = 10001;
+#ifndef RRTMG_SW_KLDS
+#define RRTMG_SW_KLDS 1      // clear-sky kernel: the item's k-distribution slice in LDS next to the 80 KB table (one workgroup per CU)
+#endif
+// the item's slice of its band's table slab -> LDS: columns ig0 .. ig0+G-1, [nrows][G] (see SwBandTab)
+__device__ __forceinline__ void sw_stage_slice(const SwTab &T, int item, double *sh_k, int nthreads) {
+  const SwBandTab &B = T.b[item_band(item)];
+  const int g = item_g(item);
+  const double *src = T.t + B.slab + item_ig0(item);
+  const int ng = B.ng, sh = g == 4 ? 2 : 1, n = B.nrows << sh;
+  for (int i = threadIdx.x; i < n; i += nthreads) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
+}
 // Two kernels are launched back to back: this one handles the cloud-free tiles with the cloud code compiled out
 // (CLD = false: no spills, chunks of 4 g-points), sw_solve_cloudy_kernel the tiles flagged by sw_prep_kernel; a
 // wavefront whose tile belongs to the other kernel exits at once.
@@ -104,33 +118,72 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
 #else
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
+#endif
+  const int k = q / ngrp;
+  const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
+#if RRTMG_SW_KLDS
+  constexpr bool kLdsK = true;
+  __shared__ double sh_k[kSwSlabMaxRows * 4];
+  sw_stage_slice(T, item, sh_k, 64 * kSwWgWaves);
+#else
+  constexpr bool kLdsK = false;
+  const double *sh_k = nullptr;
+#endif
+#if !defined(RRTMG_SW_NOLDS) || RRTMG_SW_KLDS
   __syncthreads();
 #endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = (q % ngrp) * kSwWgWaves + wave, k = q / ngrp;   // tile within the chunk
+  const int ctile = (q % ngrp) * kSwWgWaves + wave;   // tile within the chunk
   const int tile = tile0 + ctile;
   if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
-  const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
   SwPartSink sink = sw_part_sink(d, slot, col);
-  sw_solve_item<CLD>(d, T, sh_exp, item, col, scr, 64, sink);
+  sw_solve_item<CLD, kLdsK>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
 
-// The cloudy tiles: both sky streams per g-point need ~170 VGPRs, which does not go with the 8-wavefront / 80 KB-LDS
-// workgroups of the clear-sky kernel (128-VGPR cap, spills).  One wavefront per workgroup, the transmittance table
-// read through L1/L2, register budget of 2-3 waves/SIMD: measured 5 % faster than the LDS arrangement for these tiles.
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
+// The cloudy tiles: both sky streams per g-point need ~170 VGPRs, which does not go with the 128-VGPR cap of the clear-sky
+// kernel's 4 waves/SIMD (spills): register budget of 2 waves/SIMD here.  Workgroup = kSwCldWgWaves wavefronts = the same
+// pair of g-points for kSwCldWgWaves consecutive tiles, sharing the pair's k-distribution slice in LDS ([nrows][2],
+// <= 29 KB: per-lane row reads cost bank conflicts only, not the vector L1's return path); the transmittance table is
+// read through L1/L2 (RRTMG_SWC_EXPLDS=1 stages it too: 109 KB, one 8-wave workgroup per CU).
+#ifndef RRTMG_SWC_WGWAVES
+#define RRTMG_SWC_WGWAVES 4
+#endif
+#ifndef RRTMG_SWC_EXPLDS
+#define RRTMG_SWC_EXPLDS 0
+#endif
+constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
+__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
+  const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
   const int q = blockIdx.x;
-  const int ctile = q % ntile, k = q / ntile, tile = tile0 + ctile;
-  if (!d.tile_cld[tile]) return;
+  const int ctile0 = (q % ngrp) * kSwCldWgWaves, k = q / ngrp;
+  {
+    bool mine = false;
+    for (int w = 0; w < kSwCldWgWaves; ++w)
+      if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
+    if (!mine) return;
+  }
   const int id = T.sched[1][k], item = T.item[1][id], slot = item_iw0(item) >> 1;
-  const int col = tile * 64 + threadIdx.x;
+  __shared__ double sh_k[kSwSlabMaxRows * 2];
+  sw_stage_slice(T, item, sh_k, 64 * kSwCldWgWaves);
+#if RRTMG_SWC_EXPLDS
+  __shared__ double sh_exp[kExpTblN];
+  for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwCldWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
+#else
+  const double *sh_exp = T.t + T.exp_tbl;
+#endif
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ctile = ctile0 + wave, tile = tile0 + ctile;
+  if (ctile >= ntile || !d.tile_cld[tile]) return;
+  const int lane = threadIdx.x & 63;
+  const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + threadIdx.x * item_g(item);
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + lane * item_g(item);
   SwPartSink sink = sw_part_sink(d, slot, col);
-  sw_solve_item<true>(d, T, T.t + T.exp_tbl, item, col, scr, 64, sink);
+  sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
 
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T, int tile0) {
@@ -353,7 +406,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     if (last) (void)hipEventRecord(ctx->ev[0][1], s);
     if (clouds) {
       if (last) (void)hipEventRecord(ctx->ev[2][0], s);
-      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(nt * T.nitem[1]), blk, 0, s, d, T, t0, nt);
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kSwCldWgWaves - 1) / kSwCldWgWaves * T.nitem[1]), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
       if (last) (void)hipEventRecord(ctx->ev[2][1], s);
     }
     hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);

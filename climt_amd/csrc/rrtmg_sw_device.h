@@ -29,11 +29,17 @@ constexpr int kSwNGpt = 112;
 struct SwBandTab {
   int ng, gs;       // g-points in band, first g-point (0-based) of band
   int nfor, nsrc;   // rows of forref (3|4); source mixtures (1, 5 or 9)
-  long absa, absb, self, forr;   // g-point-fastest copies: [row][ng]
+  // Every per-g-point table of taumol lives in ONE g-point-fastest slab [nrows][ng] at T.t + slab (built at init);
+  // r_* = first row of each table in it.  A work item's slice of the slab -- columns ig0 .. ig0+G-1, [nrows][G] --
+  // is what the solve kernels stage in LDS, rows unchanged.
+  long slab;
+  int nrows;
+  int r_absa, r_absb, r_self, r_forr;
+  int r_rayl, r_raylb;         // rayl: 1 row (or 9 rows, band 24); raylb band 24 upper
+  int r_ex1, r_ex2;            // extra absorber rows (lower / upper)
   long sflux, irr, fac, sns;   // [js][ig]
-  long rayl, raylb;            // rayl: [ng] (or [9][ng] band 24); raylb band 24 upper
-  long ex1, ex2;               // extra absorber tables (lower / upper)
 };
+constexpr int kSwSlabMaxRows = 1800;   // bands 17 / 21 / 28: 585 + 1175 + 10 + 4 + ... rows (checked at init)
 
 // Work item of the solve kernel: G (4 or 2) consecutive g-points of one band, carried by one thread per column.
 // Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Two item sets: set 0 (chunks of
@@ -671,17 +677,21 @@ RRTMG_HD double sw_col(const SwLayerIn &s, int sp) {
 
 // Gas optical depths of the G g-points ig0 .. ig0+G-1; sets the Rayleigh optical depths.
 // `lower` = layer index <= laytrop.
-template <int BAND, int G>
-RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V<G> &taur) {
+// LDSK = true: kb -> the item's slice of the band slab, [nrows][G] (the workgroup's LDS copy); LDSK = false: kb is
+// ignored and the slab is read in place, [nrows][ng], through the vector L1.
+template <int BAND, int G, bool LDSK = false>
+RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V<G> &taur, const double *kb = nullptr) {
   using C = SwBandCfg<BAND>;
   constexpr int NG = C::ng;
+  constexpr int ST = LDSK ? G : NG;
   const SwBandTab &B = T.b[BAND - 16];
-  const double *t = T.t;
-  const KTab<G, NG> absa{t + B.absa + ig0}, absb{t + B.absb + ig0}, selfref{t + B.self + ig0}, forref{t + B.forr + ig0};
-  auto row = [&](long base) { return vload<G>(t + base + ig0); };   // a [ng] table
+  if (!LDSK) kb = T.t + B.slab + ig0;
+  auto view = [&](int r) { return KTab<G, ST>{kb + (long)r * ST}; };
+  const KTab<G, ST> absa = view(B.r_absa), absb = view(B.r_absb), selfref = view(B.r_self), forref = view(B.r_forr);
+  auto row = [&](int r) { return vload<G>(kb + (long)r * ST); };   // a one-row ([ng]) table
   V<G> taug = vsplat<G>(0.0);
   // Rayleigh: scalar per band (replicated per g at init), per g, or band 24's mixture-dependent form
-  V<G> rayl = row(B.rayl);
+  V<G> rayl = row(B.r_rayl);
   if (lower) {
     if constexpr (C::nspa == 9) {
       const SwSpec sp = sw_specparm(sw_col(s, C::lox), sw_col(s, C::loy), C::strrat, 8.0);
@@ -691,9 +701,9 @@ RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V
       if constexpr (BAND == 28) {
         taug = major;
       } else if constexpr (BAND == 24) {
-        taug = major + s.colo3 * row(B.ex1) +
+        taug = major + s.colo3 * row(B.r_ex1) +
                s.colh2o * (sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
-        const KTab<G, NG> ra{t + B.rayl + ig0};   // rayla(ig, js): [js][ig]
+        const KTab<G, ST> ra = view(B.r_rayl);   // rayla(ig, js): [js][ig]
         const V<G> r0 = ra[sp.js - 1], r1 = ra[sp.js];
         rayl = r0 + sp.fs * (r1 - r0);
       } else {
@@ -705,13 +715,13 @@ RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V
       const int i1 = (s.jp * 5 + (s.jt1 - 1));
       const V<G> m4 = sw_m4(absa, i0, i1, s);
       if constexpr (BAND == 20) {
-        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.ex1);
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.r_ex1);
       } else if constexpr (BAND == 29) {
-        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colco2 * row(B.ex1);
+        taug = s.colh2o * (m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s)) + s.colco2 * row(B.r_ex1);
       } else if constexpr (BAND == 23) {
         taug = s.colh2o * (1.029 * m4 + sw_selfterm(selfref, s) + s.forfac * sw_forinterp(forref, s));
       } else if constexpr (BAND == 25) {
-        taug = s.colh2o * m4 + s.colo3 * row(B.ex1);
+        taug = s.colh2o * m4 + s.colo3 * row(B.r_ex1);
       } else {  // 27
         taug = s.colo3 * m4;
       }
@@ -733,13 +743,13 @@ RRTMG_HD V<G> sw_taug(const SwTab &T, const SwLayerIn &s, bool lower, int ig0, V
       else if constexpr (BAND == 19) taug = s.colco2 * sw_m4(absb, i0, i1, s);
       else if constexpr (BAND == 20)
         taug = s.colh2o * (s.fac00 * absb[i0] + s.fac10 * absb[i0 + 1] + s.fac01 * absb[i1] + s.fac11 * absb[i1 + 1] +
-                           s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.ex1);
+                           s.forfac * sw_forinterp(forref, s)) + s.colch4 * row(B.r_ex1);
       else if constexpr (BAND == 22) taug = s.colo2 * 1.6 * sw_m4(absb, i0, i1, s) + 4.35e-4 * s.colo2 / (350.0 * 2.0);
-      else if constexpr (BAND == 24) { taug = s.colo2 * sw_m4(absb, i0, i1, s) + s.colo3 * row(B.ex2); rayl = row(B.raylb); }
+      else if constexpr (BAND == 24) { taug = s.colo2 * sw_m4(absb, i0, i1, s) + s.colo3 * row(B.r_ex2); rayl = row(B.r_raylb); }
       else if constexpr (BAND == 27) taug = s.colo3 * sw_m4(absb, i0, i1, s);
-      else taug = s.colco2 * sw_m4(absb, i0, i1, s) + s.colh2o * row(B.ex2);  // 29
+      else taug = s.colco2 * sw_m4(absb, i0, i1, s) + s.colh2o * row(B.r_ex2);  // 29
     } else {
-      if constexpr (BAND == 25) taug = s.colo3 * row(B.ex2);
+      if constexpr (BAND == 25) taug = s.colo3 * row(B.r_ex2);
       else taug = vsplat<G>(0.0);  // 23, 26
     }
   }
@@ -824,6 +834,7 @@ template <int G> struct SwThreadCtx {
   int b, iw0, ig0, laytrop;
   double prmu0, rmu0;      // cosine of the solar zenith angle and its reciprocal
   const double *exp_tbl;   // transmittance table: the workgroup's LDS copy on the device, T.t + T.exp_tbl on the host
+  const double *kb;        // the item's k-distribution slice in LDS (LDSK) or nullptr
   bool cloudy[G];   // any cloud in (sub-)column g
   bool any_cloudy;
   uint64_t mw[G];   // McICA cloud-mask words of the 64-layer block the sweep is in (one read per 64 layers)
@@ -836,7 +847,7 @@ template <int G> struct SwThreadCtx {
 // five more level arrays per g-point through HBM (profiles/r01_pmc_*.txt).
 // consume(g, clear, total) is called for each g-point right after its optics are ready, so that only ONE g-point's
 // ten layer operators are live at a time (register pressure).
-template <int BAND, int G, bool CLD, class Consume>
+template <int BAND, int G, bool CLD, bool LDSK, class Consume>
 RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c, int col, int l, Consume &&consume) {
   const int L = d.nlay, N = d.ncol;
   const double *exp_tbl = c.exp_tbl;
@@ -845,7 +856,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c,
   SwLayerIn s;
   sw_load_layer(d, col, l, s);
   V<G> taur;
-  const V<G> taug = sw_taug<BAND, G>(T, s, (l + 1) <= c.laytrop, c.ig0, taur);
+  const V<G> taug = sw_taug<BAND, G, LDSK>(T, s, (l + 1) <= c.laytrop, c.ig0, taur, c.kb);
   double taua = 0.0, omga = 1.0, asya = 0.0;
   const long o = ((long)c.b * L + l) * N + col;
   if (d.tauaer) { taua = d.tauaer[o]; omga = d.ssaaer[o]; asya = d.asmaer[o]; }
@@ -924,11 +935,12 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c,
 // (sub-)columns -- the total sky.  The weighted fluxes of the G g-points are added in g-point order before they
 // leave through `sink`.
 // CLD = false: the caller guarantees a cloud-free column (the cloud code is compiled out: fewer registers).
-template <int BAND, int G, bool CLD, class Sink>
-RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_tbl, int col, int ig0, double *scr, long stride, Sink &sink) {
+template <int BAND, int G, bool CLD, bool LDSK, class Sink>
+RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_tbl, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   const int L = d.nlay, N = d.ncol;
   SwThreadCtx<G> c;
   c.exp_tbl = exp_tbl;
+  c.kb = kb;
   c.b = BAND - 16;
   c.ig0 = ig0;
   c.iw0 = T.b[c.b].gs + ig0;
@@ -970,7 +982,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
   for (int g = 0; g < G; ++g) { rupc[g] = albp; rupdc[g] = albd; rup[g] = albp; rupd[g] = albd; }
   for (int l = 0; l < L; ++l) {
-    sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, [&](int g, const SwLayerOpt &oc, const SwLayerOpt &ot) {
+    sw_layer_optics<BAND, G, CLD, LDSK>(d, T, c, col, l, [&](int g, const SwLayerOpt &oc, const SwLayerOpt &ot) {
       {
         const double zr = qrcp(1.0 - rupdc[g] * oc.refd);
         const double nrup = oc.ref + (oc.trad * ((oc.tra - oc.dbt) * rupdc[g] + oc.dbt * rupc[g])) * zr;
@@ -1057,39 +1069,40 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 #pragma unroll
       for (int g = 0; g < G; ++g) { SwLayerOpt o; o.ref = 0.1 + 1e-3 * l; o.refd = 0.1; o.tra = 0.8; o.trad = 0.8; o.dbt = 0.7; down(g, o, o); }
 #else
-      sw_layer_optics<BAND, G, CLD>(d, T, c, col, l, down);
+      sw_layer_optics<BAND, G, CLD, LDSK>(d, T, c, col, l, down);
 #endif
     }
   }
 }
 
 // Dispatch of one work item (packed, see SwTab) for one column: band switch + G in {4, 2}.
-template <int BAND, bool CLD, class Sink>
-RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink) {
+template <int BAND, bool CLD, bool LDSK, class Sink>
+RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = SwBandCfg<BAND>::ng;
   if constexpr (!CLD && ng >= 4) {   // chunks of 4 exist in item set 0 (clear sky) only
-    if (g == 4) { sw_solve_thread<BAND, 4, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink); return; }
+    if (g == 4) { sw_solve_thread<BAND, 4, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb); return; }
   }
-  if constexpr (CLD || ng % 4 != 0) sw_solve_thread<BAND, 2, CLD>(d, T, exp_tbl, col, ig0, scr, stride, sink);
+  if constexpr (CLD || ng % 4 != 0) sw_solve_thread<BAND, 2, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb);
 }
-template <bool CLD, class Sink>
-RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tbl, int item, int col, double *scr, long stride, Sink &sink) {
+// LDSK / kb: see sw_taug (kb = the workgroup's LDS slice of the item's band slab, or nullptr with LDSK = false)
+template <bool CLD, bool LDSK = false, class Sink>
+RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tbl, int item, int col, double *scr, long stride, Sink &sink, const double *kb = nullptr) {
   const int g = item_g(item), ig0 = item_ig0(item);
   switch (item_band(item) + 16) {
-    case 16: sw_solve_band<16, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 17: sw_solve_band<17, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 18: sw_solve_band<18, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 19: sw_solve_band<19, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 20: sw_solve_band<20, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 21: sw_solve_band<21, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 22: sw_solve_band<22, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 23: sw_solve_band<23, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 24: sw_solve_band<24, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 25: sw_solve_band<25, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 26: sw_solve_band<26, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 27: sw_solve_band<27, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    case 28: sw_solve_band<28, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
-    default: sw_solve_band<29, CLD>(d, T, exp_tbl, g, col, ig0, scr, stride, sink); break;
+    case 16: sw_solve_band<16, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 17: sw_solve_band<17, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 18: sw_solve_band<18, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 19: sw_solve_band<19, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 20: sw_solve_band<20, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 21: sw_solve_band<21, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 22: sw_solve_band<22, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 23: sw_solve_band<23, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 24: sw_solve_band<24, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 25: sw_solve_band<25, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 26: sw_solve_band<26, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 27: sw_solve_band<27, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    case 28: sw_solve_band<28, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
+    default: sw_solve_band<29, CLD, LDSK>(d, T, exp_tbl, g, col, ig0, scr, stride, sink, kb); break;
   }
 }
 

@@ -31,38 +31,44 @@ inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
     if (B.ng != kNg[b]) { err = "reduced g-point count of band " + std::to_string(16 + b) + " differs from the compiled-in one"; return false; }
     B.nfor = 4;
     { auto it = ts.reg.find(p + "forref"); if (it != ts.reg.end()) B.nfor = (int)it->second.dims[0]; }
-    // g-point-fastest copies ([row][ng]) of the per-g-point tables ([ng][row]) for the vector loads of the kernel
-    auto gfast = [&](const std::string &n) -> long {
+    // ONE g-point-fastest slab [nrows][ng] per band holding all the per-g-point tables of taumol (the blob stores the
+    // k-tables [ng][row], the Rayleigh and extra-absorber tables [row][ng] already); SwBandTab::r_* = first rows
+    std::vector<double> slab;
+    auto append = [&](const std::string &n, bool required, bool transposed) -> int {
       auto it = ts.reg.find(p + n);
-      if (it == ts.reg.end()) return 0;
+      if (it == ts.reg.end()) { if (required) err = "reduced table '" + p + n + "' missing"; return 0; }
+      const int r0 = (int)(slab.size() / B.ng);
+      if (it->second.n == 1) {   // a band constant (rayl of most bands): replicated per g-point
+        slab.insert(slab.end(), (size_t)B.ng, ts.flat[(size_t)it->second.off]);
+        return r0;
+      }
       const long o = it->second.off, rows = it->second.n / B.ng;
-      std::vector<double> tr((size_t)it->second.n);
+      slab.resize(slab.size() + (size_t)rows * B.ng);
       for (int ig = 0; ig < B.ng; ++ig)
-        for (long r = 0; r < rows; ++r) tr[(size_t)r * B.ng + ig] = ts.flat[(size_t)o + (size_t)ig * rows + r];
-      return ts.add(p + n + "_g", tr.data(), (long)tr.size(), {(uint32_t)rows, (uint32_t)B.ng});
+        for (long r = 0; r < rows; ++r)
+          slab[(size_t)(r0 + r) * B.ng + ig] = ts.flat[(size_t)o + (transposed ? (size_t)ig * rows + r : (size_t)r * B.ng + ig)];
+      return r0;
     };
-    B.absa = gfast("absa"); B.absb = gfast("absb"); B.self = gfast("selfref"); B.forr = gfast("forref");
+    B.r_absa = append("absa", false, true); B.r_absb = append("absb", false, true);
+    B.r_self = append("selfref", false, true); B.r_forr = append("forref", false, true);
     B.sflux = off(p + "sfluxref", true); B.irr = off(p + "irradnce", true);
     B.fac = off(p + "facbrght", true); B.sns = off(p + "snsptdrk", true);
     { auto it = ts.reg.find(p + "sfluxref"); B.nsrc = it->second.dims.size() > 1 ? (int)it->second.dims[1] : 1; }
-    B.raylb = 0; B.ex1 = 0; B.ex2 = 0;
+    B.r_raylb = 0; B.r_ex1 = 0; B.r_ex2 = 0;
     const int band = 16 + b;
     if (band == 24) {
-      B.rayl = off(p + "rayla", true); B.raylb = off(p + "raylb", true);
-      B.ex1 = off(p + "abso3a", true); B.ex2 = off(p + "abso3b", true);
+      B.r_rayl = append("rayla", true, false); B.r_raylb = append("raylb", true, false);
+      B.r_ex1 = append("abso3a", true, false); B.r_ex2 = append("abso3b", true, false);
     } else {
-      auto it = ts.reg.find(p + "rayl");
-      if (it == ts.reg.end()) { err = "rayl missing for band " + std::to_string(band); return false; }
-      if (it->second.n == 1) {
-        std::vector<double> rep((size_t)B.ng, ts.flat[it->second.off]);
-        B.rayl = ts.add(p + "rayl_rep", rep.data(), B.ng, {(uint32_t)B.ng});
-      } else {
-        B.rayl = it->second.off;
-      }
-      if (band == 20) { B.ex1 = off(p + "absch4", true); }
-      if (band == 25) { B.ex1 = off(p + "abso3a", true); B.ex2 = off(p + "abso3b", true); }
-      if (band == 29) { B.ex1 = off(p + "absco2", true); B.ex2 = off(p + "absh2o", true); }
+      B.r_rayl = append("rayl", true, false);
+      if (band == 20) { B.r_ex1 = append("absch4", true, false); }
+      if (band == 25) { B.r_ex1 = append("abso3a", true, false); B.r_ex2 = append("abso3b", true, false); }
+      if (band == 29) { B.r_ex1 = append("absco2", true, false); B.r_ex2 = append("absh2o", true, false); }
     }
+    if (!err.empty()) return false;
+    B.nrows = (int)(slab.size() / B.ng);
+    if (B.nrows > kSwSlabMaxRows) { err = "band " + std::to_string(band) + " table slab has more rows than kSwSlabMaxRows"; return false; }
+    B.slab = ts.add(p + "slab_g", slab.data(), (long)slab.size(), {(uint32_t)B.nrows, (uint32_t)B.ng});
     if (!err.empty()) return false;
   }
   T.preflog = off("sw/ref/preflog", true); T.tref = off("sw/ref/tref", true); T.exp_tbl = off("sw/tbl/exp_tbl", true);
