@@ -7,9 +7,11 @@
 // Build-time experiment switches (never set in the product build; `RRTMG_HIP_BUILD_FLAGS=-D... python climt_amd/build.py`
 // builds a variant library that tools/ab*.sh time next to the product one -- results of RRTMG_ABL_* builds are WRONG
 // by design, they only answer "what does this part cost"): RRTMG_ABL_NOSCRATCH (sweep state to one row),
-// RRTMG_ABL_UNIFORMK (k-table rows collapsed), RRTMG_ABL_UNIFORMLOOKUP / NOTAUG / NOPLANCK (LW), RRTMG_ABL_NORECOMPUTE
-// (SW second-sweep optics); RRTMG_EXACT_DIV (IEEE divide instead of qdiv), RRTMG_SW_NOLDS (transmittance table left
-// in global memory), RRTMG_{SW,LW}_WAVES / RRTMG_SW_WGWAVES / RRTMG_LW_GMAX (occupancy and work-item shape).
+// RRTMG_ABL_UNIFORMK (k-table rows collapsed), RRTMG_ABL_SCALARK (k-table rows of lane 0 through the scalar cache: what
+// the per-lane gathers cost), RRTMG_ABL_UNIFORMLOOKUP / NOTAUG / NOPLANCK (LW), RRTMG_ABL_NORECOMPUTE (SW second-sweep
+// optics); RRTMG_EXACT_DIV (IEEE divide instead of qdiv), RRTMG_SW_NOLDS / RRTMG_LW_NOLDS (tables left in global
+// memory), RRTMG_SW_KLDS / RRTMG_SWC_EXPLDS (what the shortwave kernels stage in LDS), RRTMG_{SW,LW}_WAVES /
+// RRTMG_{SW,SWC,LW}_WGWAVES / RRTMG_LW_GMAX / RRTMG_LW_KU / RRTMG_LW_TILEGROUP (occupancy, work-item and launch shape).
 #define RRTMG_HD __host__ __device__ __forceinline__
 #define RRTMG_WAVE 64
 

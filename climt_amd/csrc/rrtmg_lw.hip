@@ -69,7 +69,10 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 #define RRTMG_LW_WGWAVES 4
 #endif
 constexpr int kLwWgWaves = RRTMG_LW_WGWAVES;
-constexpr int kLwTileGroup = 32;
+#ifndef RRTMG_LW_TILEGROUP
+#define RRTMG_LW_TILEGROUP 32
+#endif
+constexpr int kLwTileGroup = RRTMG_LW_TILEGROUP;
 constexpr int kLwGroupBlocks = kLwTileGroup / kLwWgWaves;
 static_assert(kLwTileGroup % kLwWgWaves == 0, "tile group must be a whole number of workgroups");
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.

@@ -1164,7 +1164,10 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   }
 
   // ---- upward sweep: kU layers at a time, their scratch rows are loaded before the first is used ----------
-  constexpr int kU = 4;
+#ifndef RRTMG_LW_KU
+#define RRTMG_LW_KU 4
+#endif
+  constexpr int kU = RRTMG_LW_KU;
   for (int lev0 = 1; lev0 <= L; lev0 += kU) {
     V<G> r_atrans[kU], r_bbugas[kU];
 #pragma unroll
