@@ -6,7 +6,8 @@
 //   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
-//   lw_solve_all_kernel  one launch: grid = tiles(64 columns) x work items (4|2 g-points of a band), block = 1 wavefront
+//   lw_solve_all_kernel  one launch per variant (clear / cloudy tiles): wavefront = tile(64 columns) x work item (4|2 g-points
+//                        of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
 //   lw_flux_kernel       <<<ncol/64, nlay+1>>>  band / g-point integration per interface
 //   lw_heat_kernel       <<<ncol/64, nlay>>>    heating rates
 #include "rrtmg_ctx.h"

@@ -5,8 +5,9 @@
 //   sw_prep_kernel      <<<ncol/64>>>            column part: laytrop, cloud flag, solar-source layers
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
 //   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
-//   sw_kiss_kernel / mask upload (mcica)         sub-column cloud mask
-//   sw_solve_all_kernel one launch: grid = tiles(64 columns) x work items (4|2 g-points of a band), block = 1 wavefront
+//   kiss_mask_kernel / mask upload (mcica)       sub-column cloud mask
+//   sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel: wavefront = tile(64 columns) x work item
+//                       (4|2 g-points of a band), workgroup = 16 | 4 tiles of one item sharing its tables in LDS
 //   sw_flux_kernel      <<<ncol/64, nlay+1>>>    g-point sum per interface
 //   sw_heat_kernel      <<<ncol/64, nlay>>>      heating rates
 #include "rrtmg_ctx.h"
