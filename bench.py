@@ -102,15 +102,17 @@ def main():
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 logic)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (with --dist-backend gloo)")
+    ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (process group, output all-gather) with a single rank too")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    multi = world > 1 or a.force_dist
     if world != a.gpus and world > 1:
         a.gpus = world
     dist = None
-    if world > 1:
+    if multi:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local)
@@ -139,8 +141,8 @@ def main():
     sizes = [(k, (L + lev) * N) for k, lev in SW_OUT] + [(k, (L + lev) * N) for k, lev in LW_OUT]
     total = sum(s for _, s in sizes)
     # Two output buffers (N>1): the RCCL all-gather of step i runs while step i+1 computes into the other one.
-    nbuf = 2 if world > 1 else 1
-    if world > 1:
+    nbuf = 2 if multi else 1
+    if multi:
         import torch
         flats = [torch.empty(total, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
         gathered = [torch.empty(total * world, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
@@ -161,7 +163,7 @@ def main():
     # spectra are enqueued in deferred mode on two streams so that they overlap on the GPU.
     ctx.set_deferred(not a.serial)
 
-    state = {"i": 0, "work": None, "enq": 0.0, "enq_sw": 0.0}
+    state = {"i": 0, "work": None, "ready": None, "enq": 0.0, "enq_sw": 0.0}
 
     def drain():
         """Wait (host side) for the all-gather in flight, if any: its source buffer may be reused afterwards."""
@@ -171,24 +173,39 @@ def main():
             torch.cuda.synchronize()
             state["work"] = None
 
+    def gather_ready():
+        """Start the all-gather of the buffer whose step is complete but not gathered yet (if any)."""
+        if state["ready"] is not None and not a.no_gather:
+            b = state["ready"]
+            state["work"] = dist.all_gather_into_tensor(gathered[b], flats[b], async_op=True)
+        state["ready"] = None
+
     def step():
+        # N>1: the all-gather of step i-1 is started right AFTER step i's kernels are enqueued, so that both its launch
+        # cost on the host and its transfer overlap step i's compute; the gather started during step i-1 read the buffer
+        # this step overwrites, so it is waited for first (it has had a whole step to finish).
         b = state["i"] % nbuf
         state["i"] += 1
         so, lo = outs[b]
+        if multi:
+            drain()
         t = time.perf_counter()
         ctx.sw_fluxes(inp, mcica=a.cloudy, out=so, memspace=1)
         state["enq_sw"] += time.perf_counter() - t
         ctx.lw_fluxes(inp, mcica=a.cloudy, out=lo, memspace=1)
         state["enq"] += time.perf_counter() - t
-        ctx.synchronize()          # this step's outputs are complete and checked; the previous gather ran meanwhile
-        if world > 1 and not a.no_gather:
-            drain()
-            state["work"] = dist.all_gather_into_tensor(gathered[b], flats[b], async_op=True)
+        if multi:
+            gather_ready()
+        ctx.synchronize()          # this step's outputs are complete and checked
+        if multi:
+            state["ready"] = b
 
     def fence():
         ctx.synchronize()
-        if world > 1:
+        if multi:
             import torch
+            drain()
+            gather_ready()         # the last step's outputs
             drain()
             dist.barrier()
             torch.cuda.synchronize()
@@ -207,7 +224,7 @@ def main():
         klw.append(ctx.kernel_ms("lw", cloudy=a.cloudy))
     fence()
     ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    if world > 1:
+    if multi:
         import torch
         t = torch.tensor([ms], dtype=torch.float64, device="cuda:%d" % local)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,7 +278,7 @@ def main():
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.destroy_process_group()
 
 
