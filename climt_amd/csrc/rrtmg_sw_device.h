@@ -550,7 +550,7 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
   } else {
     const double za1 = zgamma1 * zgamma4 + zgamma2 * zgamma3;
     const double za2 = zgamma1 * zgamma3 + zgamma2 * zgamma4;
-    const double zrk = sqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);
+    const double zrk = qsqrt(zgamma1 * zgamma1 - zgamma2 * zgamma2);   // > 0 here: (g1 - g2) = 2 (1 - w) >= 1e-6
     const double zrp = zrk * prmuz;
     const double zrp1 = 1.0 + zrp, zrm1 = 1.0 - zrp;
     const double zrk2 = 2.0 * zrk;
@@ -564,15 +564,32 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     const double zt1 = zrp1 * (za1 + zrk * zgamma4);
     const double zt2 = zrm1 * (za1 - zrk * zgamma4);
     const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-    const double zbeta = qdiv(zgamma1 - zrk, zrkg);
     double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
     const double zeu = zto1 * rmuz;
     double ze2 = zeu; if (ze2 > 500.0) ze2 = 500.0;
     double zem1, zem2;
     if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
-    const double zep1 = qrcp(zem1);
     if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
     pdbt = zeu > 500.0 ? sw_exp_lookup(exp_tbl, zeu) : zem2;
+    const double zemm = zem1 * zem1;
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRTMG_EXACT_REFTRA)
+    // The reference's quotients with numerator and denominator multiplied through by zem1 = exp(-k tau) (and
+    // zem2 * zep2 = 1 used): ONE reciprocal instead of its three (1/zem1, 1/zem2, 1/zdenr), and the diffuse pair
+    // without forming zbeta -- two reciprocals per layer operator instead of five.  Same quantities, last-place
+    // differences (the host build below keeps the reference's operation order; GPU vs reference <= 1e-9 W m-2).
+    const double zdp = zr4 + zr5 * zemm;   // = zdenr * zem1
+    if (fabs(zdp) <= eps * zem1) {
+      pref = eps;
+      ptra = zem2;
+    } else {
+      const double rd = qrcp(zdp);
+      pref = (zw * (zr1 - zr2 * zemm - (zr3 * zem2) * zem1)) * rd;
+      ptra = zem2 - (zw * (zem2 * (zt1 - zt2 * zemm) - zt3 * zem1)) * rd;
+    }
+    const double zdend = qrcp(zrkg - (zgamma1 - zrk) * zemm);
+#else
+    const double zbeta = qdiv(zgamma1 - zrk, zrkg);
+    const double zep1 = qrcp(zem1);
     const double zep2 = qrcp(zem2);
     const double zdenr = zr4 * zep1 + zr5 * zem1;
     if (zdenr >= -eps && zdenr <= eps) {
@@ -582,8 +599,8 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
       pref = qdiv(zw * (zr1 * zep1 - zr2 * zem1 - zr3 * zem2), zdenr);
       ptra = zem2 - qdiv(zem2 * zw * (zt1 * zep1 - zt2 * zem1 - zt3 * zep2), zdenr);   // zdent == zdenr
     }
-    const double zemm = zem1 * zem1;
     const double zdend = qrcp((1.0 - zbeta * zemm) * zrkg);
+#endif
     prefd = zgamma2 * (1.0 - zemm) * zdend;
     ptrad = zrk2 * zem1 * zdend;
   }
