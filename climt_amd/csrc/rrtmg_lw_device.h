@@ -914,6 +914,15 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   return s;
 }
 
+// quotient of the Pade table index x/(bpade + x): RRTMG_LW_QDIV=1 uses the quick division (see qdiv)
+#ifndef RRTMG_LW_QDIV
+#define RRTMG_LW_QDIV 0
+#endif
+#if RRTMG_LW_QDIV
+#define LW_TDIV(a, b) qdiv((a), (b))
+#else
+#define LW_TDIV(a, b) ((a) / (b))
+#endif
 #ifdef RRTMG_ABL_UNIFORMLOOKUP
 #define LW_TBLIDX(x) (((int)(x)) & 1)
 #else
@@ -1065,7 +1074,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           const double odepth_rec = rec_6 * odepth;
           gassrc = plf * (blay + dplankdn * odepth_rec) * atrans;
           odtot = odepth + odcld;
-          const double tblind = odtot / (kBpade + odtot);
+          const double tblind = LW_TDIV(odtot, kBpade + odtot);
           const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double tfactot = tfn_tbl[ittot];
           bbdtot = plf * (blay + tfactot * dplankdn);
@@ -1074,14 +1083,14 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbugas = plf * (blay + dplankup * odepth_rec);
           bbutot = plf * (blay + tfactot * dplankup);
         } else {
-          double tblind = odepth / (kBpade + odepth);
+          double tblind = LW_TDIV(odepth, kBpade + odepth);
           const int itgas = LW_TBLIDX(kTblInt * tblind + 0.5);
           odepth = tau_tbl[itgas];
           atrans = 1.0 - exp_tbl[itgas];
           const double tfacgas = tfn_tbl[itgas];
           gassrc = atrans * plf * (blay + tfacgas * dplankdn);
           odtot = odepth + odcld;
-          tblind = odtot / (kBpade + odtot);
+          tblind = LW_TDIV(odtot, kBpade + odtot);
           const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double tfactot = tfn_tbl[ittot];
           bbdtot = plf * (blay + tfactot * dplankdn);
@@ -1114,7 +1123,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           bbd = plf * (blay + dplankdn * odepth);
           bbugas = plf * (blay + dplankup * odepth);
         } else {
-          const double tblind = odepth / (kBpade + odepth);
+          const double tblind = LW_TDIV(odepth, kBpade + odepth);
           const int itr = LW_TBLIDX(kTblInt * tblind + 0.5);
           const double transc = exp_tbl[itr];
           atrans = 1.0 - transc;
