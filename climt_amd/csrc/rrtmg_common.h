@@ -11,7 +11,7 @@
 // the per-lane gathers cost), RRTMG_ABL_UNIFORMLOOKUP / NOTAUG / NOPLANCK (LW), RRTMG_ABL_NORECOMPUTE (SW second-sweep
 // optics); RRTMG_EXACT_DIV / RRTMG_EXACT_SQRT / RRTMG_EXACT_REFTRA (IEEE divide / square root, the reference's quotient order in reftra), RRTMG_SW_NOLDS / RRTMG_LW_NOLDS (tables left in global
 // memory), RRTMG_SW_KLDS / RRTMG_SWC_EXPLDS (what the shortwave kernels stage in LDS), RRTMG_{SW,LW}_WAVES /
-// RRTMG_{SW,SWC,LW}_WGWAVES / RRTMG_LW_GMAX / RRTMG_LW_KU / RRTMG_LW_TILEGROUP (occupancy, work-item and launch shape), RRTMG_LW_QDIV (quick division in the
+// RRTMG_{SW,SWC,LW}_WGWAVES / RRTMG_SWC_WAVES / RRTMG_LW_GMAX / RRTMG_LW_KU / RRTMG_LW_TILEGROUP (occupancy, work-item and launch shape), RRTMG_LW_QDIV (quick division in the
 // longwave table index).
 #define RRTMG_HD __host__ __device__ __forceinline__
 #define RRTMG_WAVE 64

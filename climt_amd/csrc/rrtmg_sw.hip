@@ -145,18 +145,21 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
 }
 
 // The cloudy tiles: both sky streams per g-point need ~170 VGPRs, which does not go with the 128-VGPR cap of the clear-sky
-// kernel's 4 waves/SIMD (spills): register budget of 2 waves/SIMD here.  Workgroup = kSwCldWgWaves wavefronts = the same
-// pair of g-points for kSwCldWgWaves consecutive tiles, sharing the pair's k-distribution slice in LDS ([nrows][2],
-// <= 29 KB: per-lane row reads cost bank conflicts only, not the vector L1's return path); the transmittance table is
-// read through L1/L2 (RRTMG_SWC_EXPLDS=1 stages it too: 109 KB, one 8-wave workgroup per CU).
+// kernel's 4 waves/SIMD (spills: measured +30 %): 3 waves/SIMD here.  Workgroup = 12 wavefronts = the same pair of
+// g-points for 12 consecutive tiles, one workgroup per CU, sharing in LDS the transmittance table (80 KB) and the pair's
+// k-distribution slice ([nrows][2], <= 29 KB): per-lane row reads and table lookups cost bank conflicts only, not the
+// vector L1's return path.  (4-wave workgroups with the slice alone, three per CU, measured 1-4 % slower.)
 #ifndef RRTMG_SWC_WGWAVES
-#define RRTMG_SWC_WGWAVES 4
+#define RRTMG_SWC_WGWAVES 12
 #endif
 #ifndef RRTMG_SWC_EXPLDS
-#define RRTMG_SWC_EXPLDS 0
+#define RRTMG_SWC_EXPLDS 1
 #endif
 constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
-__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
+#ifndef RRTMG_SWC_WAVES
+#define RRTMG_SWC_WAVES 3
+#endif
+__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
   const int q = blockIdx.x;
   const int ctile0 = (q % ngrp) * kSwCldWgWaves, k = q / ngrp;
