@@ -2,7 +2,7 @@
 //
 // Launch sequence of one rrtmg_hip_sw_fluxes call (all on ctx->stream):
 //   sw_prep_layer_kernel <<<ncol/64, nlay>>>     inatm_sw + setcoef_sw per (column, layer)
-//   sw_prep_kernel      <<<ncol/64>>>            column part: laytrop, cloud flag, solar-source layers
+//   sw_prep_kernel      <<<ncol/64, 14>>>        column part: laytrop, cloud flag; solar-source layer per band
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
 //   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
 //   kiss_mask_kernel / mask upload (mcica)       sub-column cloud mask
@@ -21,9 +21,10 @@ __global__ void __launch_bounds__(64) sw_prep_layer_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) sw_prep_layer(d, T, col, blockIdx.y);
 }
-__global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_prep_column(d, T, col);
+__global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {   // grid (tiles, bands)
+  const int col = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
+  if (col < d.ncol) sw_prep_column(d, T, col, b, b + 1);
+  if (b != 0) return;
   // tile flag: does any column of this 64-column tile have a cloud? (selects the solve kernel variant)
   const bool cld = col < d.ncol && d.anycld[col] != 0;
   const unsigned long long any = __ballot(cld);
@@ -368,7 +369,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   // ---- launches ---------------------------------------------------------------------------
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
   hipLaunchKernelGGL(sw_prep_layer_kernel, gcl, blk, 0, s, d, T);
-  hipLaunchKernelGGL(sw_prep_kernel, gcol, blk, 0, s, d, T);
+  hipLaunchKernelGGL(sw_prep_kernel, dim3(ntile, kSwNBand), blk, 0, s, d, T);
   if (d.iaer == 6) {
     double *ta = wd("aer.tau", nl * kSwNBand), *om = wd("aer.ssa", nl * kSwNBand), *as = wd("aer.asm", nl * kSwNBand);
     if (!ok) return ctx->status;

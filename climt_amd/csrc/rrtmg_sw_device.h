@@ -196,20 +196,25 @@ RRTMG_HD void sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
 }
 
 // column part (after every layer of the column is done): laytrop, cloud flag, zenith angle, solar-source layers
-RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
+// Bands b0 .. b1-1 of the solar-source bookkeeping; the column scalars (laytrop, cloud flag, clamped cos(zenith)) are
+// written by the caller that owns band 0.  The device runs one thread per (column, band) -- the per-band state
+// machines are ~500 instructions each, one thread for all 14 was the whole kernel time.
+RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col, int b0 = 0, int b1 = kSwNBand) {
   (void)T;
   const int L = d.nlay, N = d.ncol;
   int laytrop = 0, anycld = 0;
 #pragma unroll 8   // independent loads: keep several layers in flight
   for (int l = 0; l < L; ++l) {
     laytrop += ((int)d.prep[sw_prep_off(L, col, l) + P_IDX * 64] >> 28) & 1;
-    if (d.icld >= 1 && d.cldfr && d.cldfr[(long)l * N + col] > 0.0) anycld = 1;
+    if (b0 == 0 && d.icld >= 1 && d.cldfr && d.cldfr[(long)l * N + col] > 0.0) anycld = 1;
   }
-  d.laytrop[col] = laytrop;
-  d.anycld[col] = anycld;
-  double cz = d.coszen[col];
-  if (cz < 1.e-10) cz = 1.e-10;   // rrtmg_sw_rad.nomcica.f90:641-642
-  d.cossza[col] = cz;
+  if (b0 == 0) {
+    d.laytrop[col] = laytrop;
+    d.anycld[col] = anycld;
+    double cz = d.coszen[col];
+    if (cz < 1.e-10) cz = 1.e-10;   // rrtmg_sw_rad.nomcica.f90:641-642
+    d.cossza[col] = cz;
+  }
 
   // layer at which each band takes its solar source term (rrtmg_sw_taumol.f90, per-band
   // laysolfr logic; table SURVEY.md A.2).  Emulates the sequential update-and-test of the
@@ -217,33 +222,30 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col) {
   const int layreffr[kSwNBand] = {18, 30, 6, 3, 3, 8, 2, 6, 1, 2, 0, 32, 58, 49};
   const bool upper[kSwNBand] = {true, true, false, false, false, false, false, false, false, false, false, true, true, true};
   auto jp_of = [&](int lay0) { return (int)d.prep[sw_prep_off(L, col, lay0) + P_IDX * 64] & 0xff; };
-  // ONE pass over the layers with a sliding (previous, current, next) window of jp; the 14 bands' (ls, fin)
-  // states are updated side by side (same update-and-test order per band as the reference loops)
-  int ls[kSwNBand], fin[kSwNBand];
-#pragma unroll
-  for (int b = 0; b < kSwNBand; ++b) { ls[b] = upper[b] ? L : laytrop; fin[b] = 0; }
-  int jpm = 0, jpc = jp_of(0);
+  for (int b = b0; b < b1; ++b) {
+    // one pass over the layers with a sliding (previous, current, next) window of jp
+    const int ref = layreffr[b];
+    const bool up = upper[b];
+    int ls = up ? L : laytrop, fin = 0;
+    int jpm = 0, jpc = jp_of(0);
 #pragma unroll 8
-  for (int lay = 1; lay <= L; ++lay) {
-    const int jpn = (lay < L) ? jp_of(lay) : 0;
-#pragma unroll
-    for (int b = 0; b < kSwNBand; ++b) {
-      if (upper[b]) {
+    for (int lay = 1; lay <= L; ++lay) {
+      const int jpn = (lay < L) ? jp_of(lay) : 0;
+      if (up) {
         if (lay > laytrop) {
-          if (jpm < layreffr[b] && jpc >= layreffr[b]) ls[b] = lay;
-          if (lay == ls[b]) fin[b] = lay;
+          if (jpm < ref && jpc >= ref) ls = lay;
+          if (lay == ls) fin = lay;
         }
       } else if (lay <= laytrop) {
         if (b != 10) {  // band 26 has no layreffr test
-          if (jpc < layreffr[b] && jpn >= layreffr[b]) ls[b] = (lay + 1 < laytrop) ? lay + 1 : laytrop;
+          if (jpc < ref && jpn >= ref) ls = (lay + 1 < laytrop) ? lay + 1 : laytrop;
         }
-        if (lay == ls[b]) fin[b] = lay;
+        if (lay == ls) fin = lay;
       }
+      jpm = jpc; jpc = jpn;
     }
-    jpm = jpc; jpc = jpn;
+    d.laysolfr[(long)b * N + col] = fin;
   }
-#pragma unroll
-  for (int b = 0; b < kSwNBand; ++b) d.laysolfr[(long)b * N + col] = fin[b];
 }
 
 // ------------------------------------------------------------------------------------------
