@@ -79,14 +79,10 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 #ifndef RRTMG_SW_WAVES
 #define RRTMG_SW_WAVES 4
 #endif
-#ifdef RRTMG_SW_NOLDS
-constexpr int kSwWgWaves = 1;
-#else
 #ifndef RRTMG_SW_WGWAVES
 #define RRTMG_SW_WGWAVES 16
 #endif
 constexpr int kSwWgWaves = RRTMG_SW_WGWAVES;
-#endif
 constexpr int kExpTblN = 10001;
 #ifndef RRTMG_SW_KLDS
 #define RRTMG_SW_KLDS 1      // clear-sky kernel: the item's k-distribution slice in LDS next to the 80 KB table (one workgroup per CU)
@@ -125,7 +121,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
 #if RRTMG_SW_KLDS
   constexpr bool kLdsK = true;
-  __shared__ double sh_k[kSwSlabMaxRows * 4];
+  __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];   // rows are read 16 bytes at a time
   sw_stage_slice(T, item, sh_k, 64 * kSwWgWaves);
 #else
   constexpr bool kLdsK = false;
@@ -171,7 +167,7 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
     if (!mine) return;
   }
   const int id = T.sched[1][k], item = T.item[1][id], slot = item_iw0(item) >> 1;
-  __shared__ double sh_k[kSwSlabMaxRows * 2];
+  __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 2];
   sw_stage_slice(T, item, sh_k, 64 * kSwCldWgWaves);
 #if RRTMG_SWC_EXPLDS
   __shared__ double sh_exp[kExpTblN];
