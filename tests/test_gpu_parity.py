@@ -465,3 +465,37 @@ def test_update_frequency_wrapper_skips_the_kernels_between_updates():
     k = "downwelling_shortwave_flux_in_air"
     ratio = later[1][k].values[-1] / first[1][k].values[-1]
     np.testing.assert_allclose(ratio, np.cos(1.0), rtol=1e-12)   # TOA insolation scales with cos(zenith)
+
+
+def test_plain_c_host_gets_the_same_numbers_as_the_python_host(gpu_ctx, tmp_path):
+    """examples/c_host.c (gcc, C99, only include/rrtmg_hip.h) against Context.{sw,lw}_fluxes on inputs rebuilt here with
+    the same + - * / expressions: the printed fluxes agree to the printed digits."""
+    import re
+    import subprocess
+    from test_tables_and_abi import _build_c_host
+    exe = _build_c_host(tmp_path)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr
+    assert "ncol = 0 -> status 4" in p.stdout            # RRTMG_ERR_ARG instead of a Fortran stop
+    N, L = 64, 30
+    c = np.arange(N, dtype=np.float64)
+    k = np.arange(L + 1, dtype=np.float64)[:, None]
+    x = 1.0 - k / L
+    ps = 1000.0 + 0.25 * c
+    plev = 0.5 + (ps - 0.5) * x * x
+    tlev = 210.0 + 78.0 * x + 0.0 * c
+    xm = 1.0 - (np.arange(L, dtype=np.float64)[:, None] + 0.5) / L
+    one = np.ones((L, N))
+    inp = dict(play=0.5 * (plev[:-1] + plev[1:]), plev=plev, tlay=0.5 * (tlev[:-1] + tlev[1:]), tlev=tlev, tsfc=np.full(N, 289.0),
+               h2o=(1.0e-6 + 0.012 * xm * xm * xm * xm) * one, o3=(4.0e-8 + 6.0e-6 * (1.0 - xm) * (1.0 - xm)) * one,
+               co2=400.0e-6 * one, ch4=1.8e-6 * one, n2o=0.32e-6 * one, o2=0.209 * one,
+               cfc11=0 * one, cfc12=0 * one, cfc22=0 * one, ccl4=0 * one, emis=np.full((16, N), 0.98),
+               asdir=0.1 + 0.002 * c, asdif=0.1 + 0.002 * c, aldir=0.1 + 0.002 * c, aldif=0.1 + 0.002 * c, coszen=0.2 + 0.0125 * c,
+               icld=0, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1)
+    sw, lw = gpu_ctx.sw_fluxes(inp), gpu_ctx.lw_fluxes(inp)
+    rows = re.findall(r"column\s+(\d+)\s+sw toa_down (\S+) toa_up (\S+) sfc_down (\S+) hr_top (\S+)\s+lw olr (\S+) sfc_down (\S+) hr_bottom (\S+)", p.stdout)
+    assert [int(r[0]) for r in rows] == [0, 21, 42, 63]
+    for r in rows:
+        j = int(r[0])
+        want = [sw["swdflx"][L, j], sw["swuflx"][L, j], sw["swdflx"][0, j], sw["swhr"][L - 1, j], lw["uflx"][L, j], lw["dflx"][0, j], lw["hr"][0, j]]
+        np.testing.assert_allclose([float(v) for v in r[1:]], want, rtol=0, atol=6e-10)

@@ -67,3 +67,30 @@ def test_no_cpu_fallback():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in src.lower() or f in ("longwave.py",) or "oracle/" not in src, "%s references the oracle" % f
+
+
+def _build_c_host(tmp_path):
+    import subprocess
+    lib_dir = os.path.join(ROOT, "climt_amd", "_lib")
+    exe = str(tmp_path / "c_host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "examples", "c_host.c"), "-L" + lib_dir, "-lrrtmg_hip", "-Wl,-rpath," + lib_dir, "-o", exe])
+    return exe
+
+
+def test_header_is_plain_c_and_a_c_host_links_and_fails_loudly_without_a_gpu(tmp_path):
+    """include/rrtmg_hip.h is C99 (no C++ in the boundary); examples/c_host.c links against the library with gcc alone
+    and, in this GPU-less container, ends with the library's own message and a non-zero status (no CPU path)."""
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "rrtmg_hip.h")])
+    exe = _build_c_host(tmp_path)
+    import climt_amd._hip as _hip
+    try:
+        have_gpu = _hip.device_count() > 0
+    except Exception:
+        have_gpu = False
+    if have_gpu:
+        pytest.skip("a GPU is present: the run itself is covered by the gpu-marked test")
+    p = subprocess.run([exe], capture_output=True, text=True)
+    assert p.returncode == 2
+    assert "rrtmg_hip_create: status 1" in p.stderr and "no CPU path" in p.stderr
