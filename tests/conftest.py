@@ -11,6 +11,11 @@ if ROOT not in sys.path:
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long-running")
+    # the built library is not in git: a fresh checkout builds it once (hipcc cross-compiles gfx950 without a GPU)
+    lib = os.path.join(ROOT, "climt_amd", "_lib", "librrtmg_hip.so")
+    if not os.path.exists(lib):
+        from climt_amd.build import build
+        build(verbose=False)
 
 
 @pytest.fixture(scope="session")
