@@ -14,8 +14,11 @@ def pytest_configure(config):
     # the built library is not in git: a fresh checkout builds it once (hipcc cross-compiles gfx950 without a GPU)
     lib = os.path.join(ROOT, "climt_amd", "_lib", "librrtmg_hip.so")
     if not os.path.exists(lib):
-        from climt_amd.build import build
-        build(verbose=False)
+        import importlib.util   # by path: `import climt_amd` itself needs the library
+        spec = importlib.util.spec_from_file_location("_rrtmg_build", os.path.join(ROOT, "climt_amd", "build.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        mod.build(verbose=False)
 
 
 @pytest.fixture(scope="session")
