@@ -163,11 +163,13 @@ def test_native_library_is_what_runs(gpu_ctx):
     assert b"gfx950" in gpu_ctx.lib.rrtmg_hip_version()
 
 
-def test_against_live_oracle_at_larger_size(gpu_ctx):
-    """2048 columns x 60 levels against the oracle run here (reference library if it travelled, else the port)."""
+@pytest.mark.parametrize("ncol,nlay", [(2048, 60), (512, 100)])
+def test_against_live_oracle_at_larger_size(gpu_ctx, ncol, nlay):
+    """2048 columns x 60 levels (configs 2-4) and 512 x 100 (config 5's level count), McICA clouds, against the oracle run
+    here (reference library if it travelled, else the port)."""
     from climt_amd.synthetic import make_columns
     from oracle import ref_driver
-    c = make_columns(2048, 60, cloudy=True, seed=99)
+    c = make_columns(ncol, nlay, cloudy=True, seed=99)
     c.update(BASE); c.update(irng=0, permuteseed=684)
     if ref_driver.available("sw") and ref_driver.available("lw"):
         from tools.pack_tables import read_blob
@@ -178,7 +180,7 @@ def test_against_live_oracle_at_larger_size(gpu_ctx):
         esw = {}
         # the reference keeps (ngpt, ncol, nlay) automatics on the stack: feed it in chunks (kissvec is per column)
         parts_sw, parts_lw = [], []
-        for s in range(0, 2048, 256):
+        for s in range(0, ncol, 256):
             sub = {k: (v[..., s:s + 256] if isinstance(v, np.ndarray) else v) for k, v in c.items()}
             parts_sw.append(rsw.fluxes(sub, mcica=True)); parts_lw.append(rlw.fluxes(sub, mcica=True))
         esw = {k: np.concatenate([p[k] for p in parts_sw], axis=1) for k in ("swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc")}
