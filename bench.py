@@ -280,9 +280,19 @@ def main():
             res["cpu_baseline"] = cpu_baseline(L, a.cloudy)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res), flush=True)
+    else:
+        res = None
+    # The JSON line must be the LAST line on stdout: RCCL (NCCL_DEBUG=VERSION) writes its banner through C stdio, which
+    # would otherwise be flushed after it at exit.  Everyone flushes C stdio, the ranks meet, then rank 0 prints.
     if multi:
+        import ctypes
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        dist.barrier()
         dist.destroy_process_group()
+        ctypes.CDLL(None).fflush(None)
+    if res is not None:
+        print(json.dumps(res), flush=True)
 
 
 if __name__ == "__main__":
