@@ -21,6 +21,9 @@ CASES = [
      ("cloud_area_fraction_in_atmosphere_layer", "mass_content_of_cloud_ice_in_atmosphere_layer")),
     ("TestRRTMGShortwaveMCICA", "3d", climt_amd.RRTMGShortwave, dict(nx=3, ny=2, nz=15),
      ("cloud_area_fraction_in_atmosphere_layer", "mass_content_of_cloud_ice_in_atmosphere_layer")),
+    ("TestRRTMGLongwaveWithClouds", "column", climt_amd.RRTMGLongwave, dict(nz=30), ()),
+    ("TestRRTMGLongwaveWithExternalInterfaceTemperature", "column", "lw_external_tint", dict(nz=30), ()),
+    ("TestRRTMGShortwaveMCICA", "column", climt_amd.RRTMGShortwave, dict(nz=30), ()),
     ("TestSlabSurface", "column", climt_amd.SlabSurface, dict(nz=30), ("surface_material_density",)),
     ("TestSlabSurface", "3d", climt_amd.SlabSurface, dict(nx=32, ny=16, nz=28), ("surface_material_density",)),
 ]
@@ -29,6 +32,11 @@ CASES = [
 @pytest.mark.parametrize("cls,desc,component,grid_args,overwritten", CASES)
 def test_default_state_reproduces_reference_cache_states(cls, desc, component, grid_args, overwritten):
     want, _, _ = load_cache_case(cls, desc)
+    if component == "lw_external_tint":
+        # RRTMGLongwave(calculate_interface_temperature=False) adds this input at instance level (lw/component.py:180-186)
+        class component:  # noqa: N801
+            input_properties = dict(climt_amd.RRTMGLongwave.input_properties,
+                                    air_temperature_on_interface_levels={"dims": ["interface_levels", "*"], "units": "degK"})
     # input_properties is a class attribute; instances need a GPU, the state generator does not
     got = get_default_state([component], grid_state=get_grid(**grid_args))
     assert set(want) == set(got)
