@@ -157,9 +157,10 @@ constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
 #define RRTMG_SWC_WAVES 3
 #endif
 __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
-  const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
+  // launch order: tile groups, within a group the items heaviest first -- the group's prep rows (12 tiles x 0.46 MB) are
+  // fetched while its 56 items run, instead of the whole prep slab once per item
   const int q = blockIdx.x;
-  const int ctile0 = (q % ngrp) * kSwCldWgWaves, k = q / ngrp;
+  const int ctile0 = (q / T.nitem[1]) * kSwCldWgWaves, k = q % T.nitem[1];
   {
     bool mine = false;
     for (int w = 0; w < kSwCldWgWaves; ++w)
