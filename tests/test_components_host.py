@@ -12,7 +12,7 @@ import climt_amd
 from climt_amd import _sympl_compat as sc
 from climt_amd._util import get_interface_values, mass_to_volume_mixing_ratio
 from climt_amd.rrtmg import common, longwave, shortwave
-from helpers import GOLDEN, EmuContext, load_cache_case, maxdiff
+from helpers import GOLDEN, ROOT, EmuContext, load_cache_case, maxdiff
 
 
 @pytest.fixture(autouse=True)
@@ -173,3 +173,27 @@ def test_berger_orbital_series_and_time_helpers_match_oracle():
     for t in (datetime.datetime(2000, 1, 1), datetime.datetime(2000, 3, 20, 12), datetime.datetime(2016, 2, 29, 23, 59, 59), datetime.datetime(1999, 12, 31, 6)):
         assert berger.years_since_vernal_equinox(t) == orc.years_since_vernal_equinox(t)
         assert berger.fractional_day(t) == orc.fractional_day(t)
+
+
+def test_committed_bench_lines_carry_the_contract_fields():
+    """profiles/r01_bench_default*.json are bench.py's stdout on the GPU box: the keys the driver and the judge read."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_default*.json")))
+    assert files
+    for fn in files:
+        j = json.load(open(fn))
+        for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+            assert k in j, (fn, k)
+        assert j["unit"] == "columns/s" and j["higher_is_better"] is True and j["scaling"] == "weak" and j["dtype"] == "f64"
+        assert j["vs_baseline"] is None and "workload" in j["config"] and "model" not in j["config"]
+        r = j["roofline"]
+        assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and r["peak"] == 8000.0
+        assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and (r["traffic"] is None or r["traffic"] > 0)
+        # achieved = algorithmic bytes per launch / event-timed kernel duration
+        n = j["config"]["columns_per_gpu"]
+        assert abs(r["achieved"] - r["algorithmic_bytes_per_column"] * n / (r["kernel_ms"] * 1e-3) / 1e9) < 1e-6 * r["achieved"]
+        c = j["cpu_baseline"]
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "columns/s" and c["sample"]
+        assert abs(j["value"] - j["n_gpus"] * n / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
