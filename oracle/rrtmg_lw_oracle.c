@@ -357,13 +357,100 @@ static int lw_abscoef(int iceflag, int liqflag, double ciwp, double clwp, double
   return 0;
 }
 
+/* Maximum/random overlap factors of one column, rrtmg_lw_rtrnmr.f90:326-479.  Arrays keep the reference's own index
+ * 0 .. nlayers+1; cf[] is cldfrac with cf[0] = cf[nlayers+1] = 0: the reference reads cldfrac(0) and cldfrac(nlayers+1)
+ * out of bounds there, but only as a factor of products whose other factors are zero at those levels. */
+typedef struct {
+  double faccld1[OR_MAXL + 2], faccld2[OR_MAXL + 2], facclr1[OR_MAXL + 2], facclr2[OR_MAXL + 2], faccmb1[OR_MAXL + 2], faccmb2[OR_MAXL + 2];
+  double faccld1d[OR_MAXL + 2], faccld2d[OR_MAXL + 2], facclr1d[OR_MAXL + 2], facclr2d[OR_MAXL + 2], faccmb1d[OR_MAXL + 2], faccmb2d[OR_MAXL + 2];
+  int istcld[OR_MAXL + 2], istcldd[OR_MAXL + 2];
+} lw_mrfac;
+static void lw_mr_factors(int nlayers, const double *cf, const int *icldlyr /* 1-based */, lw_mrfac *m) {
+  double rat1 = 0.0, rat2 = 0.0, fmax, fmin;
+  memset(m, 0, sizeof *m);
+  m->istcld[1] = 1;
+  m->istcldd[nlayers] = 1;
+  for (int lev = 1; lev <= nlayers; ++lev) {
+    if (icldlyr[lev] == 1) {
+      m->istcld[lev + 1] = 0;
+      if (lev == nlayers) {
+        m->faccld1[lev + 1] = 0.; m->faccld2[lev + 1] = 0.; m->facclr1[lev + 1] = 0.; m->facclr2[lev + 1] = 0.; m->faccmb1[lev + 1] = 0.; m->faccmb2[lev + 1] = 0.;
+      } else if (cf[lev + 1] >= cf[lev]) {
+        m->faccld1[lev + 1] = 0.; m->faccld2[lev + 1] = 0.;
+        if (m->istcld[lev] == 1) {
+          m->facclr1[lev + 1] = 0.; m->facclr2[lev + 1] = 0.;
+          if (cf[lev] < 1.) m->facclr2[lev + 1] = (cf[lev + 1] - cf[lev]) / (1. - cf[lev]);
+          m->facclr2[lev] = 0.; m->faccld2[lev] = 0.;
+        } else {
+          fmax = cf[lev] > cf[lev - 1] ? cf[lev] : cf[lev - 1];
+          if (cf[lev + 1] > fmax) { m->facclr1[lev + 1] = rat2; m->facclr2[lev + 1] = (cf[lev + 1] - fmax) / (1. - fmax); }
+          else if (cf[lev + 1] < fmax) { m->facclr1[lev + 1] = (cf[lev + 1] - cf[lev]) / (cf[lev - 1] - cf[lev]); m->facclr2[lev + 1] = 0.; }
+          else { m->facclr1[lev + 1] = rat2; m->facclr2[lev + 1] = 0.; }
+        }
+        if (m->facclr1[lev + 1] > 0. || m->facclr2[lev + 1] > 0.) { rat1 = 1.; rat2 = 0.; } else { rat1 = 0.; rat2 = 0.; }
+      } else {
+        m->facclr1[lev + 1] = 0.; m->facclr2[lev + 1] = 0.;
+        if (m->istcld[lev] == 1) {
+          m->faccld1[lev + 1] = 0.; m->faccld2[lev + 1] = (cf[lev] - cf[lev + 1]) / cf[lev];
+          m->facclr2[lev] = 0.; m->faccld2[lev] = 0.;
+        } else {
+          fmin = cf[lev] < cf[lev - 1] ? cf[lev] : cf[lev - 1];
+          if (cf[lev + 1] <= fmin) { m->faccld1[lev + 1] = rat1; m->faccld2[lev + 1] = (fmin - cf[lev + 1]) / fmin; }
+          else { m->faccld1[lev + 1] = (cf[lev] - cf[lev + 1]) / (cf[lev] - fmin); m->faccld2[lev + 1] = 0.; }
+        }
+        if (m->faccld1[lev + 1] > 0. || m->faccld2[lev + 1] > 0.) { rat1 = 0.; rat2 = 1.; } else { rat1 = 0.; rat2 = 0.; }
+      }
+      m->faccmb1[lev + 1] = m->facclr1[lev + 1] * m->faccld2[lev] * cf[lev - 1];
+      m->faccmb2[lev + 1] = m->faccld1[lev + 1] * m->facclr2[lev] * (1. - cf[lev - 1]);
+    } else {
+      m->istcld[lev + 1] = 1;
+    }
+  }
+  for (int lev = nlayers; lev >= 1; --lev) {
+    if (icldlyr[lev] == 1) {
+      m->istcldd[lev - 1] = 0;
+      if (lev == 1) {
+        m->faccld1d[lev - 1] = 0.; m->faccld2d[lev - 1] = 0.; m->facclr1d[lev - 1] = 0.; m->facclr2d[lev - 1] = 0.; m->faccmb1d[lev - 1] = 0.; m->faccmb2d[lev - 1] = 0.;
+      } else if (cf[lev - 1] >= cf[lev]) {
+        m->faccld1d[lev - 1] = 0.; m->faccld2d[lev - 1] = 0.;
+        if (m->istcldd[lev] == 1) {
+          m->facclr1d[lev - 1] = 0.; m->facclr2d[lev - 1] = 0.;
+          if (cf[lev] < 1.) m->facclr2d[lev - 1] = (cf[lev - 1] - cf[lev]) / (1. - cf[lev]);
+          m->facclr2d[lev] = 0.; m->faccld2d[lev] = 0.;
+        } else {
+          fmax = cf[lev] > cf[lev + 1] ? cf[lev] : cf[lev + 1];
+          if (cf[lev - 1] > fmax) { m->facclr1d[lev - 1] = rat2; m->facclr2d[lev - 1] = (cf[lev - 1] - fmax) / (1. - fmax); }
+          else if (cf[lev - 1] < fmax) { m->facclr1d[lev - 1] = (cf[lev - 1] - cf[lev]) / (cf[lev + 1] - cf[lev]); m->facclr2d[lev - 1] = 0.; }
+          else { m->facclr1d[lev - 1] = rat2; m->facclr2d[lev - 1] = 0.; }
+        }
+        if (m->facclr1d[lev - 1] > 0. || m->facclr2d[lev - 1] > 0.) { rat1 = 1.; rat2 = 0.; } else { rat1 = 0.; rat2 = 0.; }
+      } else {
+        m->facclr1d[lev - 1] = 0.; m->facclr2d[lev - 1] = 0.;
+        if (m->istcldd[lev] == 1) {
+          m->faccld1d[lev - 1] = 0.; m->faccld2d[lev - 1] = (cf[lev] - cf[lev - 1]) / cf[lev];
+          m->facclr2d[lev] = 0.; m->faccld2d[lev] = 0.;
+        } else {
+          fmin = cf[lev] < cf[lev + 1] ? cf[lev] : cf[lev + 1];
+          if (cf[lev - 1] <= fmin) { m->faccld1d[lev - 1] = rat1; m->faccld2d[lev - 1] = (fmin - cf[lev - 1]) / fmin; }
+          else { m->faccld1d[lev - 1] = (cf[lev] - cf[lev - 1]) / (cf[lev] - fmin); m->faccld2d[lev - 1] = 0.; }
+        }
+        if (m->faccld1d[lev - 1] > 0. || m->faccld2d[lev - 1] > 0.) { rat1 = 0.; rat2 = 1.; } else { rat1 = 0.; rat2 = 0.; }
+      }
+      m->faccmb1d[lev - 1] = m->facclr1d[lev - 1] * m->faccld2d[lev] * cf[lev + 1];
+      m->faccmb2d[lev - 1] = m->faccld1d[lev - 1] * m->facclr2d[lev] * (1. - cf[lev + 1]);
+    } else {
+      m->istcldd[lev - 1] = 1;
+    }
+  }
+}
+
 /* rrtmg_lw driver (rrtmg_lw_rad.nomcica.f90:453-567) with cldprop (rrtmg_lw_cldprop.f90:118-272) / cldprmc
  * (rrtmg_lw_cldprmc.f90:103-250) and rtrn / rtrnmc (rrtmg_lw_rtrn.f90:261-587, rrtmg_lw_rtrnmc.f90) */
 int lw_oracle_fluxes(const lw_args *a) {
   const int N = a->ncol, L = a->nlay;
   int icld = a->icld;
   if (icld < 0 || icld > 3) icld = 2;
-  if (!a->mcica && icld >= 2) return 20; /* rtrnmr not restated */
+  const int mr = !a->mcica && icld >= 2; /* maximum/random overlap of the band cloud fractions: rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544) */
   const double fluxfac = (2.0 * asin(1.0)) * 2.e4, wtdiff = 0.5, rec_6 = 0.166667, bpade = 1.0 / 0.278;
   const double *delwave = or_f(&G.st, "lw/wvn/delwave");
   static const int icb1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
@@ -446,6 +533,13 @@ int lw_oracle_fluxes(const lw_args *a) {
       if (a->mcica) { for (int g = 0; g < NG; ++g) if (cloudy[g + (size_t)NG * (col + (size_t)N * l)]) icldlyr[l] = 1; }
       else icldlyr[l] = cldfrac[l] >= 1.e-6;
     }
+    static lw_mrfac mf;
+    if (mr) {
+      double cf1[OR_MAXL + 2]; int ic1[OR_MAXL + 2];
+      cf1[0] = 0.0; cf1[L + 1] = 0.0; ic1[0] = 0; ic1[L + 1] = 0;
+      for (int l = 0; l < L; ++l) { cf1[l + 1] = cldfrac[l]; ic1[l + 1] = icldlyr[l]; }
+      lw_mr_factors(L, cf1, ic1, &mf);
+    }
     double totuflux[OR_MAXL + 1] = {0}, totdflux[OR_MAXL + 1] = {0}, totuclfl[OR_MAXL + 1] = {0}, totdclfl[OR_MAXL + 1] = {0};
     double dtotu[OR_MAXL + 1] = {0}, dtotuc[OR_MAXL + 1] = {0};
     int igc = 0;
@@ -456,6 +550,7 @@ int lw_oracle_fluxes(const lw_args *a) {
       for (int jg = 0; jg < ngc_[ib]; ++jg, ++igc) {
         double atrans[OR_MAXL], bbugas[OR_MAXL], atot[OR_MAXL], bbutot[OR_MAXL], cf_[OR_MAXL], efcl_[OR_MAXL];
         double radld = 0.0, radclrd = 0.0;
+        double cldradd = 0.0, clrradd = 0.0, cldradu = 0.0, clrradu = 0.0, rad = 0.0;   /* rtrnmr: cloudy / clear parts, overlap carry */
         int iclddn = 0;
         for (int lev = L; lev >= 1; --lev) {
           const int l = lev - 1;
@@ -511,6 +606,18 @@ int lw_oracle_fluxes(const lw_args *a) {
               bbugas[l] = plfrac * (blay + tfacgas * dplankup);
               bbutot[l] = plfrac * (blay + tfactot * dplankup);
             }
+            if (mr) {   /* rrtmg_lw_rtrnmr.f90:572-600 */
+              if (mf.istcldd[lev] == 1) { cldradd = cldfrac[l] * radld; clrradd = radld - cldradd; rad = 0.; }
+              const double ttot = 1. - atot[l], cldsrc = bbdtot * atot[l];
+              cldradd = cldradd * ttot + cldfrac[l] * cldsrc;
+              clrradd = clrradd * (1. - atrans[l]) + (1. - cldfrac[l]) * gassrc;
+              radld = cldradd + clrradd;
+              const double radmod = rad * (mf.facclr1d[lev - 1] * (1. - atrans[l]) + mf.faccld1d[lev - 1] * ttot) - mf.faccmb1d[lev - 1] * gassrc + mf.faccmb2d[lev - 1] * cldsrc;
+              const double oldcld = cldradd - radmod, oldclr = clrradd + radmod;
+              rad = -radmod + mf.facclr2d[lev - 1] * oldclr - mf.faccld2d[lev - 1] * oldcld;
+              cldradd = cldradd + rad;
+              clrradd = clrradd - rad;
+            } else
             radld = radld - radld * (atrans[l] + efclfrac * (1. - atrans[l])) + gassrc + cf * (bbdtot * atot[l] - gassrc);
           } else {
             if (odepth <= 0.06) {
@@ -540,6 +647,18 @@ int lw_oracle_fluxes(const lw_args *a) {
           const int l = lev - 1;
           if (icldlyr[l]) {
             double gassrc = bbugas[l] * atrans[l];
+            if (mr) {   /* rrtmg_lw_rtrnmr.f90:657-682 */
+              if (mf.istcld[lev] == 1) { cldradu = cldfrac[l] * radlu; clrradu = radlu - cldradu; rad = 0.; }
+              const double ttot = 1. - atot[l], cldsrc = bbutot[l] * atot[l];
+              cldradu = cldradu * ttot + cldfrac[l] * cldsrc;
+              clrradu = clrradu * (1.0 - atrans[l]) + (1. - cldfrac[l]) * gassrc;
+              radlu = cldradu + clrradu;
+              const double radmod = rad * (mf.facclr1[lev + 1] * (1.0 - atrans[l]) + mf.faccld1[lev + 1] * ttot) - mf.faccmb1[lev + 1] * gassrc + mf.faccmb2[lev + 1] * cldsrc;
+              const double oldcld = cldradu - radmod, oldclr = clrradu + radmod;
+              rad = -radmod + mf.facclr2[lev + 1] * oldclr - mf.faccld2[lev + 1] * oldcld;
+              cldradu = cldradu + rad;
+              clrradu = clrradu - rad;
+            } else
             radlu = radlu - radlu * (atrans[l] + efcl_[l] * (1.0 - atrans[l])) + gassrc + cf_[l] * (bbutot[l] * atot[l] - gassrc);
             if (a->idrv) d_radlu = d_radlu * cf_[l] * (1.0 - atot[l]) + d_radlu * (1.0 - cf_[l]) * (1.0 - atrans[l]);
           } else {

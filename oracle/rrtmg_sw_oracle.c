@@ -471,6 +471,28 @@ int sw_oracle_fluxes(const sw_args *a) {
       }
     }
     if (err) break;
+    /* aerosol optics by band: iaer = 10 as given, iaer = 6 mixed from the six ECMWF types (rrtmg_sw_rad.nomcica.f90:693-727) */
+    static double ztaua[OR_MAXL][NB], zomga[OR_MAXL][NB], zasya[OR_MAXL][NB];
+    for (int l = 0; l < L; ++l)
+      for (int b = 0; b < NB; ++b) {
+        const long o = ((long)b * L + l) * N + col;
+        ztaua[l][b] = iaer == 10 && a->tauaer ? a->tauaer[o] : 0.0;
+        zomga[l][b] = iaer == 10 && a->ssaaer ? a->ssaaer[o] : 1.0;
+        zasya[l][b] = iaer == 10 && a->asmaer ? a->asmaer[o] : 0.0;
+        if (iaer == 6) {
+          const double *rt = or_f(&G.st, "sw/aer/rsrtaua"), *rp = or_f(&G.st, "sw/aer/rsrpiza"), *ra = or_f(&G.st, "sw/aer/rsrasya");
+          double t = 0.0, w = 0.0, g = 0.0;
+          for (int ia = 0; ia < 6; ++ia) {
+            const double e = a->ecaer ? a->ecaer[((long)ia * L + l) * N + col] : 0.0;
+            t = t + rt[b + NB * ia] * e;
+            w = w + rt[b + NB * ia] * e * rp[b + NB * ia];
+            g = g + rt[b + NB * ia] * e * rp[b + NB * ia] * ra[b + NB * ia];
+          }
+          if (t == 0.0) { t = 0.0; g = 0.0; w = 1.0; }
+          else { if (w != 0.0) g = g / w; if (t != 0.0) w = w / t; }
+          ztaua[l][b] = t; zomga[l][b] = w; zasya[l][b] = g;
+        }
+      }
     double bbfu[OR_MAXL + 1] = {0}, bbfd[OR_MAXL + 1] = {0}, bbcu[OR_MAXL + 1] = {0}, bbcd[OR_MAXL + 1] = {0};
     int iw = 0;
     for (int b = 0; b < NB; ++b) {
@@ -491,9 +513,7 @@ int sw_oracle_fluxes(const sw_args *a) {
         zdbt[L] = 0.0; ztra[L] = 0.0; ztrad[L] = 0.0; zref[L] = albp; zrefd[L] = albd; zrup[L] = albp; zrupd[L] = albd;
         for (int jk = 0; jk < L; ++jk) {
           const int ikl = L - 1 - jk;
-          const long o = ((long)b * L + ikl) * N + col;
-          const double ptaua = iaer == 10 && a->tauaer ? a->tauaer[o] : 0.0, pomga = iaer == 10 && a->ssaaer ? a->ssaaer[o] : 1.0;
-          const double pasya = iaer == 10 && a->asmaer ? a->asmaer[o] : 0.0;
+          const double ptaua = ztaua[ikl][b], pomga = zomga[ikl][b], pasya = zasya[ikl][b];
           double cf, ptauc = 0.0, pomgc = 1.0, pasyc = 0.0;
           if (icld == 0) cf = 0.0;
           else if (a->mcica) { cf = cloudy[iw + (size_t)NG * (col + (size_t)N * ikl)] ? 1.0 : 0.0; if (cf > 0) { ptauc = ctau[ikl][b]; pomgc = cssa[ikl][b]; pasyc = casm[ikl][b]; } }

@@ -208,6 +208,128 @@ def slab_surface_cases():
         print("slab surface cache", desc, len(save))
 
 
+
+# ---- option coverage: aerosols, direct cloud optics, every ice / liquid parameterisation, grey surfaces -------------------
+def _opt_base(seed, ncol=24, nlay=40, overcast_layers=False):
+    from climt_amd.synthetic import make_columns, overcast
+    c = make_columns(ncol, nlay, cloudy=True, seed=seed)
+    if overcast_layers:
+        c = overcast(c)
+    c.pop("lat")
+    c.update(icld=1, iaer=0, adjes=1.0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=37 + seed)
+    return c
+
+
+def _opt_aer6(c, rng):
+    nlay, ncol = c["play"].shape
+    # ECMWF aerosol optical thickness at 0.55 um, six types, concentrated in the lowest third of the column
+    prof = np.exp(-np.arange(nlay) / (nlay / 6.0))[None, :, None]
+    c["ecaer"] = np.ascontiguousarray(rng.uniform(0.0, 0.08, (6, nlay, ncol)) * prof)
+    c["ecaer"][3, :, ::5] = 0.0          # a type absent in some columns
+    c["ecaer"][:, nlay - 3:, :] = 0.0    # aerosol-free layers: the (0, 1, 0) branch of the mixing
+    c["iaer"] = 6
+
+
+def _opt_aer10(c, rng, nb):
+    nlay, ncol = c["play"].shape
+    prof = np.exp(-np.arange(nlay) / (nlay / 5.0))[None, :, None]
+    c["tauaer"] = np.ascontiguousarray(rng.uniform(0.0, 0.05, (nb, nlay, ncol)) * prof)
+    if nb == 14:
+        c["ssaaer"] = np.ascontiguousarray(rng.uniform(0.75, 1.0, (nb, nlay, ncol)))
+        c["asmaer"] = np.ascontiguousarray(rng.uniform(0.3, 0.8, (nb, nlay, ncol)))
+        c["iaer"] = 10
+
+
+def _opt_inflag0(c, rng, nb):
+    nlay, ncol = c["play"].shape
+    cld = c["cldfr"] > 0
+    tau = rng.uniform(0.2, 6.0, (nlay, ncol, nb)) * cld[:, :, None]
+    tau[:, ::4, :] *= 0.0                # cloud fraction > 0 with zero optical depth: the tauctot gate
+    c["taucld"] = np.ascontiguousarray(tau)
+    if nb == 14:
+        g = rng.uniform(0.7, 0.9, (nlay, ncol, nb))
+        c["ssacld"] = np.ascontiguousarray(rng.uniform(0.85, 0.999999, (nlay, ncol, nb)))
+        c["asmcld"] = np.ascontiguousarray(g)
+        c["fsfcld"] = np.ascontiguousarray(g * g)
+    c["inflg"] = 0
+    # the water paths stay in the state (cwp gate) but must not be used
+    c["cicewp"] = c["cicewp"] * (rng.uniform(0, 1, (nlay, ncol)) > 0.5)
+    c["cicewp"][:, ::8] = 0.0; c["cliqwp"][:, ::8] = 0.0     # neither water path nor optical depth: gate closed
+
+
+def _opt_sizes(c, rng, iceflg, liqflg):
+    nlay, ncol = c["play"].shape
+    lo, hi = {0: (10.0, 120.0), 1: (13.0, 130.0), 2: (5.0, 131.0), 3: (5.0, 140.0)}[iceflg]
+    c["reice"] = np.ascontiguousarray(rng.uniform(lo, hi, (nlay, ncol)))
+    c["reice"][:, 0] = lo; c["reice"][:, 1] = hi          # the table end points (index clamps)
+    c["reliq"] = np.ascontiguousarray(rng.uniform(2.5, 60.0, (nlay, ncol)))
+    c["reliq"][:, 2] = 2.5; c["reliq"][:, 3] = 60.0
+    c["iceflg"], c["liqflg"] = iceflg, liqflg
+
+
+def _opt_emis(c, rng):
+    ncol = c["play"].shape[1]
+    c["emis"] = np.ascontiguousarray(rng.uniform(0.90, 0.99, (16, ncol)))
+
+
+def option_cases():
+    """name -> (spectrum, mcica, inputs): every non-default option of the path with its own seeded inputs."""
+    cases = {}
+    def add(name, spectrum, mcica, seed, build, overcast_layers=False, **flags):
+        rng = np.random.default_rng(9000 + seed)
+        c = _opt_base(seed, overcast_layers=overcast_layers)
+        build(c, rng)
+        c.update(flags)
+        cases[name] = (spectrum, mcica, c)
+    # shortwave (reference k-distribution data: physical parity)
+    add("sw_aer6_clear", "sw", False, 1, _opt_aer6, icld=0)
+    add("sw_aer6_mcica", "sw", True, 2, _opt_aer6, icld=2)
+    add("sw_aer10_overcast", "sw", False, 3, lambda c, r: _opt_aer10(c, r, 14), overcast_layers=True)
+    add("sw_aer10_mcica", "sw", True, 4, lambda c, r: _opt_aer10(c, r, 14), icld=1)
+    add("sw_inflag0_overcast", "sw", False, 5, lambda c, r: _opt_inflag0(c, r, 14), overcast_layers=True)
+    add("sw_inflag0_mcica", "sw", True, 6, lambda c, r: _opt_inflag0(c, r, 14), icld=2)
+    for ice in (2, 3):
+        add("sw_ice%d_overcast" % ice, "sw", False, 10 + ice, lambda c, r, ice=ice: _opt_sizes(c, r, ice, 1), overcast_layers=True)
+        add("sw_ice%d_mcica" % ice, "sw", True, 20 + ice, lambda c, r, ice=ice: _opt_sizes(c, r, ice, 1), icld=3 if ice == 3 else 1)
+    # longwave (synthetic k-tables: algorithm parity)
+    def emis_aer(c, r):
+        _opt_emis(c, r); _opt_aer10(c, r, 16)
+    add("lw_emis_aer_clear", "lw", False, 31, emis_aer, icld=0)
+    add("lw_emis_aer_random", "lw", False, 32, emis_aer, icld=1)
+    add("lw_emis_aer_maxrand_idrv", "lw", False, 33, emis_aer, icld=2, idrv=1)
+    add("lw_emis_aer_mcica", "lw", True, 34, emis_aer, icld=2, idrv=1)
+    add("lw_inflag0_random", "lw", False, 35, lambda c, r: (_opt_inflag0(c, r, 16), _opt_emis(c, r)), icld=1)
+    add("lw_inflag0_maxrand", "lw", False, 36, lambda c, r: _opt_inflag0(c, r, 16), icld=2)
+    add("lw_inflag0_mcica", "lw", True, 37, lambda c, r: (_opt_inflag0(c, r, 16), _opt_emis(c, r)), icld=1)
+    add("lw_inflag1_random", "lw", False, 38, lambda c, r: _opt_emis(c, r), icld=1, inflg=1)
+    for ice, liq in ((0, 0), (0, 1), (1, 0), (2, 1), (3, 1), (2, 0), (3, 0)):
+        add("lw_ice%d_liq%d_random" % (ice, liq), "lw", False, 40 + 4 * ice + liq, lambda c, r, i=ice, q=liq: (_opt_sizes(c, r, i, q), _opt_emis(c, r)), icld=1)
+        add("lw_ice%d_liq%d_mcica" % (ice, liq), "lw", True, 60 + 4 * ice + liq, lambda c, r, i=ice, q=liq: _opt_sizes(c, r, i, q), icld=2)
+    return cases
+
+
+def reference_option_cases():
+    """ref_opt_<name>.npz: inputs stored IN the fixture (self-contained), outputs of the reference Fortran."""
+    from oracle.ref_driver import RefLW, RefSW
+    from tools.pack_tables import read_blob
+    from tools.synth_lw_tables import fill_reference_from_blob
+    sw = RefSW()
+    blob = read_blob(os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin"))
+    lw = RefLW()
+    lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+    for name, (spectrum, mcica, c) in option_cases().items():
+        save = {"in/" + k: v for k, v in c.items() if isinstance(v, np.ndarray)}
+        save.update({"flag/" + k: np.array(v) for k, v in c.items() if not isinstance(v, np.ndarray)})
+        save["flag/_mcica"] = np.array(int(mcica))
+        r = (sw if spectrum == "sw" else lw).fluxes(dict(c), mcica=mcica)
+        keys = ("swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc") if spectrum == "sw" else \
+               ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc") + (("duflx_dt", "duflxc_dt") if c.get("idrv") else ())
+        for k in keys:
+            save["%s/%s" % (spectrum, k)] = r[k]
+        assert all(np.all(np.isfinite(r[k])) for k in keys), name
+        np.savez_compressed(os.path.join(OUT, "ref_opt_%s.npz" % name), **save)
+        print("option case", name, {k: float(np.abs(r[k]).max()) for k in keys[:2]})
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -221,3 +343,4 @@ if __name__ == "__main__":
     instellation_cases()
     berger_cases()
     slab_surface_cases()
+    reference_option_cases()

@@ -183,3 +183,19 @@ def load_lwmr_case(name):
     c["cldfr"] = np.ascontiguousarray(z["in/cldfr"])
     c.update(icld=int(z["flag/icld"]), iaer=0, inflg=2, iceflg=1, liqflg=1, idrv=int(z["flag/idrv"]))
     return c, {k[3:]: z[k] for k in z.files if k.startswith("lw/")}
+
+
+# ---- option-coverage fixtures (self-contained: the inputs are stored in the file) -----------------------------
+OPT_CASES = tuple(sorted(f[len("ref_opt_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("ref_opt_") and f.endswith(".npz")))
+
+
+def load_opt_case(name):
+    """-> (spectrum 'sw' | 'lw', mcica flag, inputs at the C-ABI boundary, expected outputs of the reference Fortran)."""
+    z = np.load(os.path.join(GOLDEN, "ref_opt_%s.npz" % name))
+    c = {k[3:]: np.ascontiguousarray(z[k]) for k in z.files if k.startswith("in/")}
+    flags = {k[5:]: z[k].item() for k in z.files if k.startswith("flag/")}
+    mcica = bool(flags.pop("_mcica"))
+    c.update(flags)
+    spectrum = name.split("_")[0]
+    exp = {k[3:]: z[k] for k in z.files if k.startswith(spectrum + "/")}
+    return spectrum, mcica, c, exp

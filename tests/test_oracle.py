@@ -136,3 +136,30 @@ def test_slab_surface_oracle_reproduces_reference_caches(desc):
                             1029 * one, 1500 * one, 2000 * one, 4181.3 * one, 50 * one, 2 * one, 25 * one)
     assert np.allclose(t, [(100.0 + 25.0) / (1029 * 50 * 4181.3), 100.0 / (1500 * 2 * 2000), 0.0, 0.0], rtol=1e-15)
     assert np.array_equal(d, [50.0, 2.0, 2.0, 50.0])
+
+
+def _opt_cases():
+    from helpers import OPT_CASES
+    return OPT_CASES
+
+
+@pytest.mark.parametrize("case", _opt_cases())
+def test_oracle_options_match_reference_fortran(case):
+    """The C restatement on every non-default option (aerosols, direct cloud optics, ice/liquid parameterisations,
+    grey surfaces) against the reference Fortran's outputs on the inputs stored in the fixture."""
+    from helpers import load_opt_case
+    spectrum, mcica, c, exp = load_opt_case(case)
+    out = (port.PortSW() if spectrum == "sw" else port.PortLW()).fluxes(c, mcica=mcica)
+    for k, v in exp.items():
+        assert maxdiff(out[k], v) <= 1e-9, (k, maxdiff(out[k], v))
+
+
+def test_oracle_rtrnmr_matches_reference_fortran():
+    """Non-McICA maximum/random overlap (rtrnmr incl. dF/dT) of the C restatement against the reference Fortran."""
+    from helpers import LWMR_CASES, load_lwmr_case
+    for case in LWMR_CASES:
+        c, exp = load_lwmr_case(case)
+        out = port.PortLW().fluxes(c, mcica=False)
+        for k, v in exp.items():
+            if v.shape == out[k].shape:
+                assert maxdiff(out[k], v) <= 1e-11, (case, k, maxdiff(out[k], v))
