@@ -87,6 +87,26 @@ class DeviceArray:
             pass
 
 
+class Stream:
+    """A non-blocking HIP stream (does not synchronise with the null stream)."""
+
+    def __init__(self):
+        s = C.c_void_p()
+        _ck(lib().hipStreamCreateWithFlags(C.byref(s), C.c_uint(1)), "hipStreamCreateWithFlags")   # hipStreamNonBlocking
+        self.s = s.value
+
+    def synchronize(self):
+        _ck(lib().hipStreamSynchronize(C.c_void_p(self.s)), "hipStreamSynchronize")
+
+    def __del__(self):
+        try:
+            if self.s:
+                lib().hipStreamDestroy(C.c_void_p(self.s))
+                self.s = None
+        except Exception:
+            pass
+
+
 class Event:
     def __init__(self):
         e = C.c_void_p()

@@ -25,7 +25,7 @@ class RRTMGError(RuntimeError):
 
 class SwArgs(C.Structure):
     _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld iaer inflgsw iceflgsw liqflgsw dyofyr isolvar "
-                                     "irng permuteseed reserved0").split()]
+                                     "irng permuteseed shard_col0 shard_ncol reserved0").split()]
                 + [(n, _f64) for n in "adjes scon solcycfrac".split()]
                 + [(n, _vp) for n in ("bndsolvar indsolvar play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr "
                                       "asdir asdif aldir aldif coszen cldfr taucld ssacld asmcld fsfcld cicewp cliqwp reice "
@@ -34,7 +34,7 @@ class SwArgs(C.Structure):
 
 class LwArgs(C.Structure):
     _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld idrv inflglw iceflglw liqflglw irng permuteseed "
-                                     "reserved0").split()]
+                                     "shard_col0 shard_ncol reserved0").split()]
                 + [(n, _vp) for n in ("play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr cfc11vmr cfc12vmr "
                                       "cfc22vmr ccl4vmr emis cldfr taucld cicewp cliqwp reice reliq tauaer cldfmcl "
                                       "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()])
@@ -79,6 +79,7 @@ def load_library():
     lib.rrtmg_hip_lw_tables_synthetic.argtypes = [_vp]
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
     lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
+    lib.rrtmg_hip_stream_wait.argtypes = [_vp, _vp]
     lib.rrtmg_hip_zenith_angle.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _vp]
     lib.rrtmg_hip_slab_surface.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(SlabArgs)]
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
@@ -102,9 +103,9 @@ _LW_FIELDS = dict(play="play", plev="plev", tlay="tlay", tlev="tlev", tsfc="tsfc
                   emis="emis", cldfr="cldfr", taucld="taucld", cicewp="cicewp", cliqwp="cliqwp", reice="reice", reliq="reliq",
                   tauaer="tauaer", cldfmcl="cldfmcl")
 _SW_FLAGS = dict(icld="icld", iaer="iaer", inflg="inflgsw", iceflg="iceflgsw", liqflg="liqflgsw", dyofyr="dyofyr",
-                 isolvar="isolvar", irng="irng", permuteseed="permuteseed")
+                 isolvar="isolvar", irng="irng", permuteseed="permuteseed", shard_col0="shard_col0", shard_ncol="shard_ncol")
 _LW_FLAGS = dict(icld="icld", idrv="idrv", inflg="inflglw", iceflg="iceflglw", liqflg="liqflglw", irng="irng",
-                 permuteseed="permuteseed")
+                 permuteseed="permuteseed", shard_col0="shard_col0", shard_ncol="shard_ncol")
 SW_OUT = (("swuflx", 1), ("swdflx", 1), ("swhr", 0), ("swuflxc", 1), ("swdflxc", 1), ("swhrc", 0))
 LW_OUT = (("uflx", 1), ("dflx", 1), ("hr", 0), ("uflxc", 1), ("dflxc", 1), ("hrc", 0))
 
@@ -163,6 +164,10 @@ class Context:
     def synchronize(self):
         """Wait for all enqueued work; in deferred mode this is where device-side errors are raised."""
         self._ck(self.lib.rrtmg_hip_synchronize(self.h))
+
+    def stream_wait(self, other_stream):
+        """`other_stream` (hipStream_t) waits, on the device, for everything enqueued so far on this context's streams."""
+        self._ck(self.lib.rrtmg_hip_stream_wait(self.h, _vp(other_stream)))
 
     def zenith_angle(self, lat_deg, lon_deg, julian_centuries, out=None, memspace=0, ncol=None):
         """Zenith angle (radians) of every column; host arrays, or device pointers with memspace=1 (then `ncol`)."""

@@ -30,10 +30,18 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   RRTMG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   if (!ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_lw, hipStreamNonBlocking));
-  if (!ctx->err_dev) RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
+  if (!ctx->err_dev) {
+    RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
+    RRTMG_HIP_CHECK(ctx, hipMemset(ctx->err_dev, 0, 64));
+  }
+  for (int w = 0; w < 2; ++w)
+    for (int k = 0; k < 2; ++k)
+      if (!ctx->kiss_ev[w][k]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->kiss_ev[w][k], hipEventDisableTiming));
   for (int w = 0; w < 4; ++w)
     for (int k = 0; k < 2; ++k)
       if (!ctx->ev[w][k]) RRTMG_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[w][k]));
+  for (int w = 0; w < 2; ++w)
+    if (!ctx->sync_ev[w]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->sync_ev[w], hipEventDisableTiming));
   return RRTMG_OK;
 }
 
@@ -80,6 +88,14 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
   if (ctx->sw_tab_dev) (void)hipFree(ctx->sw_tab_dev);
   if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
   if (ctx->err_dev) (void)hipFree(ctx->err_dev);
+  for (int w = 0; w < 4; ++w)
+    for (int k = 0; k < 2; ++k)
+      if (ctx->ev[w][k]) (void)hipEventDestroy(ctx->ev[w][k]);
+  for (int w = 0; w < 2; ++w)
+    for (int k = 0; k < 2; ++k)
+      if (ctx->kiss_ev[w][k]) (void)hipEventDestroy(ctx->kiss_ev[w][k]);
+  for (int w = 0; w < 2; ++w)
+    if (ctx->sync_ev[w]) (void)hipEventDestroy(ctx->sync_ev[w]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_lw) (void)hipStreamDestroy(ctx->stream_lw);
   rrtmg::free_sw_desc(ctx);
@@ -100,15 +116,29 @@ int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
   if (!ctx) return RRTMG_ERR_ARG;
   if (ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream_lw));
-  // deferred calls: collect the device-side error flags now (the former Fortran `stop` conditions)
+  // deferred calls: collect the device-side error flags now (the former Fortran `stop` conditions).  Deferred calls do
+  // not clear their flag (atomicMax accumulates over every call enqueued since the last collection); it is cleared here.
   if (ctx->pending[0] || ctx->pending[1]) {
     int herr[2] = {0, 0};
+    const int zero[2] = {0, 0};
     RRTMG_HIP_CHECK(ctx, hipMemcpy(herr, ctx->err_dev, sizeof herr, hipMemcpyDeviceToHost));
+    RRTMG_HIP_CHECK(ctx, hipMemcpy(ctx->err_dev, zero, sizeof zero, hipMemcpyHostToDevice));
     const bool p0 = ctx->pending[0], p1 = ctx->pending[1];
     ctx->pending[0] = ctx->pending[1] = false;
-    if (p0 && herr[0]) return ctx->fail(herr[0], "shortwave: %s", status_message(herr[0]));
-    if (p1 && herr[1]) return ctx->fail(herr[1], "longwave: %s", status_message(herr[1]));
+    const int e0 = p0 ? herr[0] : 0, e1 = p1 ? herr[1] : 0;
+    if (e0 && e1) return ctx->fail(e0, "shortwave: %s; longwave (status %d): %s", status_message(e0), e1, status_message(e1));
+    if (e0) return ctx->fail(e0, "shortwave: %s", status_message(e0));
+    if (e1) return ctx->fail(e1, "longwave: %s", status_message(e1));
   }
+  return RRTMG_OK;
+}
+int rrtmg_hip_stream_wait(rrtmg_ctx *ctx, void *other_stream) {
+  if (!ctx || !ctx->stream || !ctx->stream_lw) return RRTMG_ERR_ARG;
+  hipStream_t o = (hipStream_t)other_stream;
+  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->sync_ev[0], ctx->stream));
+  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->sync_ev[1], ctx->stream_lw));
+  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(o, ctx->sync_ev[0], 0));
+  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(o, ctx->sync_ev[1], 0));
   return RRTMG_OK;
 }
 int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on) {

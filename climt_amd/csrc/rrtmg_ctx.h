@@ -31,7 +31,10 @@ struct rrtmg_ctx {
   // and the partial-flux planes stay bounded (~0.23 MB per column and spectrum at 60 layers); env RRTMG_HIP_CHUNK_TILES
   int chunk_tiles = 512;
   // KISS jump-ahead operators [sw|lw]: host copy, the key they were built for, the device buffer they were uploaded to
-  std::vector<uint32_t> kiss_host[2];
+  std::vector<uint32_t> kiss_host[2][2];   // two staging copies per spectrum: a rebuild never waits for the previous upload
+  hipEvent_t kiss_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // recorded after the upload from kiss_host[w][k]
+  int kiss_slot[2] = {0, 0};
+  hipEvent_t sync_ev[2] = {nullptr, nullptr};   // rrtmg_hip_stream_wait: "everything enqueued so far" on stream / stream_lw
   int kiss_key[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
   const void *kiss_dev[2] = {nullptr, nullptr};
   std::string err;
@@ -100,5 +103,6 @@ int lw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob);
 int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
                     const double *play, const double *cldfrac, double *cldfmcl);
 // Mersenne-twister CDF stream of the reference (mcica_random_numbers.f90:77-302) -> bit mask on host
-void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw,
+                  int col0 = 0, int ncol_total = 0);
 }  // namespace rrtmg

@@ -159,6 +159,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (!ctx->lw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_lw_init has not been called");
   if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
   if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
+  if (a->shard_ncol != 0 && (a->shard_col0 < 0 || a->shard_col0 + a->ncol > a->shard_ncol)) return ctx->fail(RRTMG_ERR_ARG, "shard_col0/shard_ncol do not contain ncol columns");
   int rc = ctx_prepare_device(ctx);
   if (rc) return rc;
   hipStream_t s = (ctx->deferred && a->memspace == 1) ? ctx->stream_lw : ctx->stream;
@@ -237,7 +238,12 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   }
   if (!ok) return ctx->status;
   d.err = ctx->err_dev + 1;   // [0] shortwave, [1] longwave
-  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+  const bool deferred_call = ctx->deferred && a->memspace == 1;
+  if (!deferred_call) {
+    // a synchronous call owns its flag; flags of calls still pending from deferred mode are collected first
+    if (ctx->pending[0] || ctx->pending[1]) { const int prc = rrtmg_hip_synchronize(ctx); if (prc) return prc; }
+    RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+  }   // deferred: the flag accumulates (atomicMax) until rrtmg_hip_synchronize collects and clears it
 
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
   hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
@@ -261,7 +267,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
         if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
         else cf.assign(a->cldfr, a->cldfr + nl);
         std::vector<uint64_t> hm;
-        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw);
+        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw, a->shard_col0, a->shard_ncol);
         RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
         RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
       }

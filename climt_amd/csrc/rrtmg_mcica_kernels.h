@@ -25,12 +25,18 @@ static const uint32_t *kiss_jumps_device(rrtmg_ctx *ctx, int which, int nsub, in
   bool same = ctx->kiss_dev[which] == dev;
   for (int i = 0; i < 4; ++i) same = same && ctx->kiss_key[which][i] == key[i];
   if (!same) {
-    (void)hipStreamSynchronize(s);   // the host copy below may still be the source of an earlier upload
-    kiss_build_jumps(nsub, nlay, icld, seed, ctx->kiss_host[which]);
-    if (hipMemcpyAsync(dev, ctx->kiss_host[which].data(), ctx->kiss_host[which].size() * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
+    // Two host staging copies, used alternately: the one rebuilt now was the source of the upload before the previous
+    // one, which has long completed (its event is waited for, without stalling the stream), so a component that redraws
+    // its seed on every call does not serialise the SW / LW streams.
+    const int slot = ctx->kiss_slot[which] ^= 1;
+    std::vector<uint32_t> &host = ctx->kiss_host[which][slot];
+    (void)hipEventSynchronize(ctx->kiss_ev[which][slot]);
+    kiss_build_jumps(nsub, nlay, icld, seed, host);
+    if (hipMemcpyAsync(dev, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s) != hipSuccess) {
       ctx->fail(RRTMG_ERR_HIP, "upload of the KISS jump table failed");
       return nullptr;
     }
+    (void)hipEventRecord(ctx->kiss_ev[which][slot], s);
     for (int i = 0; i < 4; ++i) ctx->kiss_key[which][i] = key[i];
     ctx->kiss_dev[which] = dev;
   }

@@ -27,6 +27,15 @@ struct MT {
     st[623] = st[396] ^ twist(st[623], st[0]);
     cur = 0;
   }
+  // advance the stream by n draws without tempering them (state regenerations only)
+  void skip(long n) {
+    while (n > 0) {
+      if (cur >= 624) next_state();
+      const long k = n < 624 - cur ? n : 624 - cur;
+      cur += (int)k;
+      n -= k;
+    }
+  }
   double real() {
     if (cur >= 624) next_state();
     uint32_t y = st[cur++];
@@ -43,12 +52,20 @@ struct MT {
 };
 }  // namespace
 
-void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw) {
+// col0 / ncol_total: the ncol columns are columns col0 .. col0+ncol-1 of a grid of ncol_total columns (a shard of a
+// multi-GPU run; ncol_total <= 0: not sharded).  The draws of the other shards' columns are skipped, so the shard gets
+// exactly the bits the unsharded call gives these columns.
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw,
+                  int col0, int ncol_total) {
   mask.assign((size_t)nsub * nw * ncol, 0ull);
   if (icld == 0) return;
   MT mt(seed);
   const double cldmin = 1.0e-20;
-  for (int g = 0; g < nsub; ++g)
+  const long per_col = icld == 3 ? 1 : nlay;                                    // draws per (sub-column, column)
+  const long before = ncol_total > 0 ? (long)col0 * per_col : 0;
+  const long after = ncol_total > 0 ? (long)(ncol_total - col0 - ncol) * per_col : 0;
+  for (int g = 0; g < nsub; ++g) {
+    mt.skip(before);
     for (int c = 0; c < ncol; ++c) {
       double cdf_prev = 0.0, cmax = 0.0;
       if (icld == 3) cmax = mt.real();
@@ -70,6 +87,8 @@ void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double
         if (cdf >= 1.0 - cf) mask[((size_t)g * nw + (l >> 6)) * ncol + c] |= 1ull << (l & 63);
       }
     }
+    mt.skip(after);
+  }
 }
 
 }  // namespace rrtmg

@@ -269,6 +269,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (!ctx->sw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_sw_init has not been called");
   if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
   if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
+  if (a->shard_ncol != 0 && (a->shard_col0 < 0 || a->shard_col0 + a->ncol > a->shard_ncol)) return ctx->fail(RRTMG_ERR_ARG, "shard_col0/shard_ncol do not contain ncol columns");
   int rc = ctx_prepare_device(ctx);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
@@ -361,7 +362,12 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (!ok) return ctx->status;
   if (!a->swuflx || !a->swdflx || !a->swhr || !a->swuflxc || !a->swdflxc || !a->swhrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   d.err = ctx->err_dev;
-  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+  const bool deferred_call = ctx->deferred && a->memspace == 1;
+  if (!deferred_call) {
+    // a synchronous call owns its flag; flags of calls still pending from deferred mode are collected first
+    if (ctx->pending[0] || ctx->pending[1]) { const int prc = rrtmg_hip_synchronize(ctx); if (prc) return prc; }
+    RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
+  }   // deferred: the flag accumulates (atomicMax) until rrtmg_hip_synchronize collects and clears it
 
   // ---- launches ---------------------------------------------------------------------------
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
@@ -389,7 +395,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
         if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
         else cf.assign(a->cldfr, a->cldfr + nl);
         std::vector<uint64_t> hm;
-        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw);
+        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw, a->shard_col0, a->shard_ncol);
         RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
         RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
       }

@@ -1,10 +1,42 @@
-"""Column sharding of the RRTMG path across ranks (one process per GPU, torch.distributed).
+"""Column sharding of the RRTMG path across GPUs: one process per GPU, RCCL over xGMI for the output gather.
 
-Every routine of the path is column-independent, so ranks own contiguous column blocks, the
-tables are replicated and the only communication is one all-gather that reassembles the output arrays
-(RCCL over xGMI with the "nccl" backend on MI355X; "gloo" in the CPU tests).  Sharded == unsharded, bit for bit.
+Every routine of the path is column-independent (rrtmg_lw_rad.nomcica.f90:453 and rrtmg_sw_rad.nomcica.f90:587
+are serial loops over independent columns), so ranks own contiguous column blocks, the tables are replicated and nothing is
+exchanged while computing.  The only communication reassembles the outputs, and it is optional:
+
+    gather = "all"   one ncclAllGather of a flat device buffer holding the rank's 12 (14 with dF/dT) output arrays
+             "root"  the blocks are sent to rank 0 only (grouped ncclSend / ncclRecv)
+             "none"  every rank keeps its block (a model that is itself domain-decomposed needs nothing else)
+
+`RcclComm` binds librccl.so directly (ctypes: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv) and
+runs on its own HIP stream, which is made to wait for the radiation kernels on the device (rrtmg_hip_stream_wait): the gather
+of step i runs under the kernels of step i+1, into the other half of a double buffer.  `TorchComm` carries the same interface
+over torch.distributed on host memory -- the world-size-2 gloo tests on CPU, and a fallback if RCCL cannot be initialised.
+
+Sharded == unsharded, bit for bit: kissvec sub-columns are seeded per column; for the Mersenne twister, whose reference stream
+is ONE sequence over (sub-column, column, layer), every rank passes its block's position (shard_col0, shard_ncol) and the
+generator skips the other ranks' draws (rrtmg_mt.cpp).  When a block boundary is not a multiple of the 64-column tile, a column
+may run the other solve-kernel variant (clear-sky / cloudy tile), which changes the shortwave by round-off only.
 """
+import ctypes as C
+import os
+import socket
+import struct
+
 import numpy as np
+
+from ._lib import LW_OUT, SW_OUT
+
+# column axis of every boundary-level array (None: not a per-column array) -- explicit, never guessed from shapes
+COLUMN_AXIS = dict(
+    play=1, plev=1, tlay=1, tlev=1, h2o=1, o3=1, co2=1, ch4=1, n2o=1, o2=1, cfc11=1, cfc12=1, cfc22=1, ccl4=1,
+    cldfr=1, cicewp=1, cliqwp=1, reice=1, reliq=1,                       # [layer][column]
+    tsfc=0, asdir=0, asdif=0, aldir=0, aldif=0, coszen=0, lat=0,          # [column]
+    emis=1,                                                               # [band][column]
+    taucld=1, ssacld=1, asmcld=1, fsfcld=1, cldfmcl=1,                    # [layer][column][band | g-point]
+    tauaer=2, ssaaer=2, asmaer=2, ecaer=2,                                # [band | type][layer][column]
+    bndsolvar=None, indsolvar=None,
+)
 
 
 def column_block(ncol, world, rank):
@@ -14,41 +46,336 @@ def column_block(ncol, world, rank):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def slice_columns(inp, lo, hi, ncol):
-    """Column slice of a boundary-level input dict (the column axis is the last axis for 1-D/2-D inputs and for the
-    [band][layer][column] aerosol arrays, the middle axis for [layer][column][band] cloud optics)."""
+def slice_columns(inp, lo, hi):
+    """Columns [lo, hi) of a boundary-level input dict, by the explicit per-name axis map."""
     out = {}
     for k, v in inp.items():
         if not isinstance(v, np.ndarray):
             out[k] = v
-        elif v.ndim == 3 and v.shape[1] == ncol and v.shape[2] != ncol:
-            out[k] = np.ascontiguousarray(v[:, lo:hi, :])
-        elif v.shape[-1] == ncol:
-            out[k] = np.ascontiguousarray(v[..., lo:hi])
-        else:
+            continue
+        if k not in COLUMN_AXIS:
+            raise KeyError("slice_columns: no column axis known for array '%s'" % k)
+        ax = COLUMN_AXIS[k]
+        if ax is None:
             out[k] = v
+        else:
+            idx = [slice(None)] * v.ndim
+            idx[ax] = slice(lo, hi)
+            out[k] = np.ascontiguousarray(v[tuple(idx)])
     return out
 
 
+# ---- communicators ---------------------------------------------------------------------------------------------
+def tcp_broadcast(payload, rank, world, addr=None, port=None, timeout=120.0):
+    """Rank 0's `payload` (bytes) on every rank: a minimal rendezvous over TCP (MASTER_ADDR, RRTMG_HIP_RDZV_PORT or
+    MASTER_PORT + 17) used to hand out the RCCL unique id without torch."""
+    if world == 1:
+        return payload
+    addr = addr or os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(port or os.environ.get("RRTMG_HIP_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 17))
+    if rank == 0:
+        srv = socket.socket()
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind((addr, port))
+        srv.listen(world)
+        srv.settimeout(timeout)
+        for _ in range(world - 1):
+            conn, _ = srv.accept()
+            conn.sendall(struct.pack("<I", len(payload)) + payload)
+            conn.close()
+        srv.close()
+        return payload
+    import time
+    t0 = time.time()
+    while True:
+        try:
+            s = socket.create_connection((addr, port), timeout=5.0)
+            break
+        except OSError:
+            if time.time() - t0 > timeout:
+                raise
+            time.sleep(0.05)
+    def rd(n):
+        b = b""
+        while len(b) < n:
+            chunk = s.recv(n - len(b))
+            if not chunk:
+                raise ConnectionError("rendezvous connection closed")
+            b += chunk
+        return b
+    n = struct.unpack("<I", rd(4))[0]
+    data = rd(n)
+    s.close()
+    return data
+
+
+class _NcclUniqueId(C.Structure):
+    _fields_ = [("internal", C.c_char * 128)]
+
+
+class RcclError(RuntimeError):
+    pass
+
+
+class RcclComm:
+    """librccl.so through ctypes: the communicator, its HIP stream, all-gather and gather-to-root of fp64 buffers."""
+    NCCL_FLOAT64 = 8   # ncclDataType_t: ncclFloat64 / ncclDouble
+
+    def __init__(self, rank, world, device, broadcast=None):
+        from . import _hip
+        self.rank, self.world = rank, world
+        self.lib = None
+        for name in (os.environ.get("RRTMG_HIP_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"):
+            if not name:
+                continue
+            try:
+                self.lib = C.CDLL(name)
+                break
+            except OSError:
+                continue
+        if self.lib is None:
+            raise RcclError("librccl.so not loadable")
+        L = self.lib
+        L.ncclGetErrorString.restype = C.c_char_p
+        L.ncclGetUniqueId.argtypes = [C.POINTER(_NcclUniqueId)]
+        L.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, _NcclUniqueId, C.c_int]
+        L.ncclAllGather.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclSend.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclRecv.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        L.ncclCommDestroy.argtypes = [C.c_void_p]
+        L.ncclGroupStart.argtypes = []
+        L.ncclGroupEnd.argtypes = []
+        _hip.set_device(device)
+        uid = _NcclUniqueId()
+        if rank == 0:
+            self._ck(L.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+        if world > 1:      # (string_at: a c_char array field would stop at the first NUL byte)
+            raw = (broadcast or tcp_broadcast)(C.string_at(C.addressof(uid), 128) if rank == 0 else b"", rank, world)
+            if len(raw) != 128:
+                raise RcclError("unique-id exchange returned %d bytes" % len(raw))
+            C.memmove(C.addressof(uid), raw, 128)
+        self.comm = C.c_void_p()
+        self._ck(L.ncclCommInitRank(C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        self.stream = _hip.Stream()
+        self.kind = "rccl"
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise RcclError("%s failed: %s" % (what, self.lib.ncclGetErrorString(rc).decode()))
+
+    def all_gather(self, send_ptr, recv_ptr, count):
+        """recv[r * count : (r+1) * count] = rank r's send[0:count] (fp64), on the communicator's stream."""
+        self._ck(self.lib.ncclAllGather(send_ptr, recv_ptr, count, self.NCCL_FLOAT64, self.comm, self.stream.s), "ncclAllGather")
+
+    def gather_root(self, send_ptr, recv_ptr, count):
+        """Rank 0 receives every other rank's block into recv[r * count ...]; its own block stays where it is."""
+        L = self.lib
+        self._ck(L.ncclGroupStart(), "ncclGroupStart")
+        if self.rank == 0:
+            for r in range(1, self.world):
+                self._ck(L.ncclRecv(recv_ptr + 8 * count * r, count, self.NCCL_FLOAT64, r, self.comm, self.stream.s), "ncclRecv")
+        else:
+            self._ck(L.ncclSend(send_ptr, count, self.NCCL_FLOAT64, 0, self.comm, self.stream.s), "ncclSend")
+        self._ck(L.ncclGroupEnd(), "ncclGroupEnd")
+
+    def wait(self):
+        self.stream.synchronize()
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+class TorchComm:
+    """The same interface over torch.distributed on HOST arrays (numpy): gloo in the CPU tests."""
+
+    def __init__(self, dist, rank, world):
+        self.dist, self.rank, self.world = dist, rank, world
+        self.stream = None
+        self.kind = "torch." + dist.get_backend()
+
+    def all_gather(self, send, recv, count):
+        import torch
+        parts = [torch.empty(count, dtype=torch.float64) for _ in range(self.world)]
+        self.dist.all_gather(parts, torch.from_numpy(send[:count]))
+        for r, p in enumerate(parts):
+            recv[r * count:(r + 1) * count] = p.numpy()
+
+    def gather_root(self, send, recv, count):
+        import torch
+        t = torch.from_numpy(send[:count])
+        if self.rank == 0:
+            parts = [torch.empty(count, dtype=torch.float64) for _ in range(self.world)]
+            self.dist.gather(t, parts, dst=0)
+            for r in range(1, self.world):
+                recv[r * count:(r + 1) * count] = parts[r].numpy()
+        else:
+            self.dist.gather(t, None, dst=0)
+
+    def wait(self):
+        pass
+
+    def close(self):
+        pass
+
+
+# ---- the sharded radiation step ----------------------------------------------------------------------------------
+class ShardedRadiation:
+    """This rank's block of a column grid, resident on its GPU, and the (double-buffered) gather of the outputs.
+
+        sr = ShardedRadiation(ctx, comm, ncol_total, nlay, gather="all")
+        sr.set_inputs(full_inputs)          # slices this rank's columns and uploads them once
+        for ...: b = sr.step(mcica=True)    # SW || LW on the context's two streams, then the gather of buffer b
+        sr.finish(); full = sr.gathered_host(b)
+
+    `ctx` is a climt_amd._lib.Context (device memory) -- or the tests' host emulation, in which case the buffers are numpy.
+    """
+
+    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2):
+        if gather not in ("all", "root", "none"):
+            raise ValueError("gather must be 'all', 'root' or 'none'")
+        self.ctx, self.comm, self.gather, self.device = ctx, comm, gather, device
+        self.rank, self.world = comm.rank, comm.world
+        self.ncol_total, self.nlay = ncol_total, nlay
+        self.lo, self.hi = column_block(ncol_total, self.world, self.rank)
+        self.ncol = self.hi - self.lo
+        self.width = -(-ncol_total // self.world)          # widest block: the per-rank stride of the gathered buffer
+        self.names = [k for k, _ in SW_OUT] + [k for k, _ in LW_OUT] + (["duflx_dt", "duflxc_dt"] if idrv else [])
+        self.levs = [lev for _, lev in SW_OUT] + [lev for _, lev in LW_OUT] + ([1, 1] if idrv else [])
+        self.idrv = idrv
+        self.block = sum((nlay + lev) * self.width for lev in self.levs)       # doubles per rank in the gathered buffer
+        self.nbuf = nbuf if self.world > 1 and gather != "none" else 1
+        gathered_here = gather == "all" or (gather == "root" and self.rank == 0)
+        if device:
+            from . import _hip
+            self._hip = _hip
+            self.flat = [_hip.DeviceArray((self.block,)) for _ in range(self.nbuf)]
+            self.full = [_hip.DeviceArray((self.block * self.world,)) if gathered_here and self.world > 1 else None for _ in range(self.nbuf)]
+            self.events = [_hip.Event() for _ in range(self.nbuf)]
+            ctx.set_deferred(True)
+        else:
+            self.flat = [np.zeros(self.block) for _ in range(self.nbuf)]
+            self.full = [np.zeros(self.block * self.world) if gathered_here and self.world > 1 else None for _ in range(self.nbuf)]
+        self.inflight = [False] * self.nbuf
+        self.i = 0
+        self.inp = None
+        self._keep = None
+
+    # layout of one rank's block: the arrays one after the other, each [levels][that rank's columns]
+    def offsets(self, ncol):
+        off, out = 0, {}
+        for k, lev in zip(self.names, self.levs):
+            out[k] = (off, self.nlay + lev)
+            off += (self.nlay + lev) * ncol
+        return out
+
+    def set_inputs(self, inp, already_local=False):
+        """Boundary-level inputs: the full grid (sliced here) or, with already_local, this rank's block."""
+        local = dict(inp) if already_local else slice_columns(inp, self.lo, self.hi)
+        local.pop("lat", None)
+        local.update(shard_col0=self.lo, shard_ncol=self.ncol_total)
+        if self.device:
+            self._keep = {k: self._hip.DeviceArray.from_host(v) for k, v in local.items() if isinstance(v, np.ndarray)}
+            self.inp = {k: v.ptr for k, v in self._keep.items()}
+            self.inp.update({k: v for k, v in local.items() if not isinstance(v, np.ndarray)})
+            self.inp.update(ncol=self.ncol, nlay=self.nlay)
+        else:
+            self.inp = local
+
+    def _out(self, b):
+        offs = self.offsets(self.ncol)
+        if self.device:
+            base = self.flat[b].ptr
+            o = {k: base + 8 * off for k, (off, _) in offs.items()}
+        else:
+            o = {k: self.flat[b][off:off + n * self.ncol].reshape(n, self.ncol) for k, (off, n) in offs.items()}
+        sw = {k: o[k] for k, _ in SW_OUT}
+        lw = {k: o[k] for k in self.names[len(SW_OUT):]}
+        return sw, lw
+
+    def step(self, mcica=False):
+        """One LW+SW pass over this rank's block into buffer b = step number mod nbuf; starts its gather; returns b."""
+        b = self.i % self.nbuf
+        self.i += 1
+        if self.inflight[b]:                      # the gather that read this buffer (nbuf steps ago) must be done
+            if self.device:
+                self.events[b].synchronize()
+            self.inflight[b] = False
+        sw, lw = self._out(b)
+        ms = 1 if self.device else 0
+        self.ctx.sw_fluxes(self.inp, mcica=mcica, out=sw, memspace=ms)
+        self.ctx.lw_fluxes(self.inp, mcica=mcica, out=lw, memspace=ms)
+        if self.world > 1 and self.gather != "none":
+            if self.device:
+                self.ctx.stream_wait(self.comm.stream.s)      # device-side: the gather starts when the kernels are done
+            send = self.flat[b].ptr if self.device else self.flat[b]
+            recv = (self.full[b].ptr if self.device else self.full[b]) if self.full[b] is not None else None
+            if self.gather == "all":
+                self.comm.all_gather(send, recv, self.block)
+            else:
+                self.comm.gather_root(send, recv if recv is not None else 0, self.block)
+            if self.device:
+                self.events[b].record(self.comm.stream.s)
+            self.inflight[b] = True
+        if self.device:
+            self.ctx.synchronize()                # this step's kernels are complete and their status checked
+        return b
+
+    def finish(self):
+        """Wait for every gather in flight."""
+        for b in range(self.nbuf):
+            if self.inflight[b]:
+                if self.device:
+                    self.events[b].synchronize()
+                self.inflight[b] = False
+        self.comm.wait()
+
+    def local_host(self, b):
+        """This rank's outputs of buffer b as numpy arrays [levels][local columns]."""
+        flat = self.flat[b].download() if self.device else self.flat[b]
+        return {k: flat[off:off + n * self.ncol].reshape(n, self.ncol).copy() for k, (off, n) in self.offsets(self.ncol).items()}
+
+    def gathered_host(self, b):
+        """The full-grid outputs of buffer b as numpy arrays (ranks that hold them: all, or rank 0 with gather='root')."""
+        if self.world == 1 or self.gather == "none":
+            return self.local_host(b)
+        if self.full[b] is None:
+            return None
+        full = self.full[b].download() if self.device else self.full[b]
+        mine = self.local_host(b)
+        cols = {k: [] for k in self.names}
+        for r in range(self.world):
+            rlo, rhi = column_block(self.ncol_total, self.world, r)
+            n_r = rhi - rlo
+            for k, (off, n) in self.offsets(n_r).items():
+                if r == self.rank and self.gather == "root":
+                    cols[k].append(mine[k])     # gather='root' leaves rank 0's own block in place
+                else:
+                    cols[k].append(full[r * self.block + off: r * self.block + off + n * n_r].reshape(n, n_r))
+        return {k: np.concatenate(v, axis=1) for k, v in cols.items()}
+
+
 def sharded_fluxes(ctx, inp, which, mcica, dist, world, rank):
-    """Compute this rank's column block with `ctx` and all-gather the outputs; returns full-size arrays on every
-    rank.  `dist` is torch.distributed (initialised)."""
-    import torch
+    """Convenience for host arrays: this rank's block of `inp` through ctx.{sw,lw}_fluxes, outputs all-gathered with
+    torch.distributed; returns full-size arrays on every rank.  (The device-resident path is ShardedRadiation.)"""
     nlay, ncol = inp["play"].shape
     lo, hi = column_block(ncol, world, rank)
-    local = slice_columns(inp, lo, hi, ncol)
+    local = slice_columns(inp, lo, hi)
+    local.update(shard_col0=lo, shard_ncol=ncol)
     out = ctx.sw_fluxes(local, mcica=mcica) if which == "sw" else ctx.lw_fluxes(local, mcica=mcica)
+    comm = TorchComm(dist, rank, world)
     width = -(-ncol // world)
     full = {}
     for k, v in out.items():
-        pad = np.zeros((v.shape[0], width))
-        pad[:, : hi - lo] = v
-        t = torch.from_numpy(pad)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t)
+        count = v.shape[0] * width
+        send = np.zeros(count)
+        send[: v.size] = v.ravel()
+        recv = np.zeros(count * world)
+        comm.all_gather(send, recv, count)
         cols = []
-        for r, p in enumerate(parts):
+        for r in range(world):
             rlo, rhi = column_block(ncol, world, r)
-            cols.append(p.numpy()[:, : rhi - rlo])
+            cols.append(recv[r * count: r * count + v.shape[0] * (rhi - rlo)].reshape(v.shape[0], rhi - rlo))
         full[k] = np.concatenate(cols, axis=1)
     return full

@@ -6,7 +6,7 @@ init_ozone :1130-1143) restricted to what the components of this package read, s
 examples/gmd_aquaplanet.py can build its initial state without the reference installed:
 
     grid  = get_grid(nx=32, ny=16, nz=28)
-    state = get_default_state([RRTMGLongwave(), RRTMGShortwave(), SlabSurface()], grid_state=grid)
+    state = get_default_state([RRTMGLongwave(allow_synthetic_tables=True), RRTMGShortwave(), SlabSurface()], grid_state=grid)
 
 Everything here is O(grid) numpy run once at start-up -- not part of the per-step hot path, hence no kernel.
 The values are pinned by the reference's own golden caches: their `*_stepping-1.cache` files hold the complete

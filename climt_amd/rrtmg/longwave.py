@@ -1,11 +1,15 @@
 """RRTMGLongwave -- drop-in for climt.RRTMGLongwave (climt/_components/rrtmg/lw/component.py:30-522)
 running on librrtmg_hip.so (MI355X).
 
-NOTE: the reference checkout lacks the longwave k-distribution data file; the table blob shipped with
-this build therefore carries SYNTHETIC k-tables (Context.lw_tables_synthetic()).  The algorithm is
-parity-checked against the reference Fortran on those tables; physical fluxes need the real blob
-(tools/pack_tables.py lw, no code change)."""
+NOTE: the reference checkout lacks the longwave k-distribution data file (rrtmg_lw_k_g.f90 is a missing
+blob), so the table file shipped with this build carries SYNTHETIC k-tables (Context.lw_tables_synthetic()).
+The algorithm is parity-checked against the reference Fortran on those tables, but the fluxes are not
+physical.  The component therefore FAILS CLOSED: constructing it on synthetic tables raises, unless the
+caller opts in with allow_synthetic_tables=True (or RRTMG_HIP_ALLOW_SYNTHETIC_LW=1) -- the parity tests and
+the benchmark do.  With the reference data at hand: `python tools/pack_tables.py lw <dir with rrtmg_lw_k_g.f90>`
+writes climt_amd/data/rrtmg_lw_data.bin (or point RRTMG_HIP_LW_DATA at the packed file); no code change."""
 import logging
+import os
 
 import numpy as np
 
@@ -67,9 +71,10 @@ class RRTMGLongwave(TendencyComponent):
 
     def __init__(self, calculate_change_up_flux=False, cloud_overlap_method=None, cloud_optical_properties="liquid_and_ice_clouds",
                  cloud_ice_properties="ebert_curry_two", cloud_liquid_water_properties="radius_dependent_absorption",
-                 calculate_interface_temperature=True, mcica=False, random_number_generator="mersenne_twister", device=0, **kwargs):
-        """Same keyword arguments and defaults as climt.RRTMGLongwave (lw/component.py:167-178); `device`
-        (GPU ordinal) is the one addition."""
+                 calculate_interface_temperature=True, mcica=False, random_number_generator="mersenne_twister", device=0,
+                 allow_synthetic_tables=False, **kwargs):
+        """Same keyword arguments and defaults as climt.RRTMGLongwave (lw/component.py:167-178); additions: `device`
+        (GPU ordinal) and `allow_synthetic_tables` (see the module docstring)."""
         self.input_properties = RRTMGLongwave.input_properties.copy()
         self._calc_dflxdt = 1 if calculate_change_up_flux else 0
         self._mcica = mcica
@@ -99,8 +104,13 @@ class RRTMGLongwave(TendencyComponent):
         self._ctx = make_context(device)
         self._ctx.lw_init(self._Cpd)
         if self._ctx.lw_tables_synthetic():
-            logging.warning("RRTMGLongwave: the longwave k-distribution tables in this build are SYNTHETIC "
-                            "(the reference data file rrtmg_lw_k_g.f90 was not available); fluxes are not physical.")
+            msg = ("RRTMGLongwave: the longwave k-distribution tables in this build are SYNTHETIC (the reference data "
+                   "file rrtmg_lw_k_g.f90 was not available); fluxes and heating rates are not physical.")
+            if not (allow_synthetic_tables or os.environ.get("RRTMG_HIP_ALLOW_SYNTHETIC_LW", "") not in ("", "0")):
+                self._ctx.close()
+                raise RuntimeError(msg + "  Pack the real tables (tools/pack_tables.py lw) or pass allow_synthetic_tables=True "
+                                         "/ set RRTMG_HIP_ALLOW_SYNTHETIC_LW=1 to run on them knowingly.")
+            logging.warning(msg)
         # derivative of the upward flux w.r.t. surface temperature (idrv = 1), kept on the instance: the
         # reference never hands these arrays back (its Cython shim would fail with calculate_change_up_flux=True)
         self.change_in_upward_flux_with_surface_temperature = None

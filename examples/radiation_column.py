@@ -27,7 +27,7 @@ def main():
     a = ap.parse_args()
 
     sun = climt_amd.Instellation()
-    lw = climt_amd.UpdateFrequencyWrapper(climt_amd.RRTMGLongwave(), timedelta(hours=1))
+    lw = climt_amd.UpdateFrequencyWrapper(climt_amd.RRTMGLongwave(allow_synthetic_tables=True), timedelta(hours=1))
     sw = climt_amd.UpdateFrequencyWrapper(climt_amd.RRTMGShortwave(), timedelta(hours=1))
     slab = climt_amd.SlabSurface()
     stepper = climt_amd.AdamsBashforth(lw, sw, slab)

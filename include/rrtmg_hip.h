@@ -75,6 +75,9 @@ const char *rrtmg_hip_version(void);
 /* HIP stream (hipStream_t) the work of this context is enqueued on (longwave uses a second one in deferred mode). */
 void *rrtmg_hip_stream(rrtmg_ctx *ctx);
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
+/* Device-side ordering: `other_stream` (a hipStream_t of the caller, e.g. the one an RCCL gather of the outputs is issued on)
+ * waits for everything enqueued so far on this context's streams; the host does not block. */
+int rrtmg_hip_stream_wait(rrtmg_ctx *ctx, void *other_stream);
 /* Deferred mode (off by default).  When on, rrtmg_hip_{sw,lw}_fluxes calls with memspace == 1 (device-resident
  * arrays) return as soon as their kernels are enqueued -- shortwave and longwave on separate streams, so the two
  * overlap on the GPU -- and the device-side error flags (the reference's `stop` conditions) are reported by the
@@ -140,6 +143,11 @@ typedef struct rrtmg_sw_args {
   int32_t dyofyr, isolvar;
   int32_t irng;         /* McICA RNG: 0 kissvec, 1 Mersenne twister */
   int32_t permuteseed;  /* McICA changeSeed */
+  /* Column shard of a larger grid (multi-GPU): this call's columns are columns shard_col0 .. shard_col0+ncol-1 of a grid of
+   * shard_ncol columns; 0, 0 = not sharded.  Only the Mersenne twister needs it: the reference draws ONE stream in
+   * (sub-column, column, layer) order (mcica_subcol_gen_sw.f90:360-367), so a shard skips the other shards' draws and
+   * reproduces the unsharded masks bit for bit.  kissvec seeds are per column and ignore it. */
+  int32_t shard_col0, shard_ncol;
   int32_t reserved0;
   double adjes, scon, solcycfrac;
   const double *bndsolvar;   /* [14] (host) or NULL -> ones */
@@ -174,6 +182,7 @@ typedef struct rrtmg_lw_args {
   int32_t icld, idrv;
   int32_t inflglw, iceflglw, liqflglw;
   int32_t irng, permuteseed;
+  int32_t shard_col0, shard_ncol;                    /* see rrtmg_sw_args */
   int32_t reserved0;
   const double *play, *plev, *tlay, *tlev, *tsfc;
   const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;

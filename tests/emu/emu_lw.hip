@@ -12,7 +12,7 @@
 using namespace rrtmg;
 
 namespace rrtmg {
-void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw, int col0 = 0, int ncol_total = 0);
 }
 
 // the clear-sky variant for cloud-free columns, as the device picks it per tile
@@ -91,7 +91,7 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
       } else if (a->irng == 0) {
         for (int c = 0; c < N; ++c) kiss_mask_column(N, L, kLwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err, c);
       } else {
-        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, a->cldfr, mask, d.nw);
+        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, a->cldfr, mask, d.nw, a->shard_col0, a->shard_ncol);
         d.mask = mask.data();
       }
       for (int c = 0; c < N; ++c) lw_anymask_column(d, c);

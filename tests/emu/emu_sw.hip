@@ -18,7 +18,7 @@
 using namespace rrtmg;
 
 namespace rrtmg {
-void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw);
+void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw, int col0 = 0, int ncol_total = 0);
 }
 
 static void emu_solve(const SwDev &d, const SwTab &T) {
@@ -112,7 +112,7 @@ extern "C" int emu_sw_fluxes(const rrtmg_sw_args *a, const char *blob_path, doub
       } else if (a->irng == 0) {
         for (int c = 0; c < N; ++c) kiss_mask_column(N, L, kSwNGpt, d.icld, a->permuteseed, d.play, d.cldfr, d.mask, d.nw, d.err, c);
       } else {
-        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, a->cldfr, mask, d.nw);
+        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, a->cldfr, mask, d.nw, a->shard_col0, a->shard_ncol);
         d.mask = mask.data();
       }
     }

@@ -199,3 +199,40 @@ def load_opt_case(name):
     spectrum = name.split("_")[0]
     exp = {k[3:]: z[k] for k in z.files if k.startswith(spectrum + "/")}
     return spectrum, mcica, c, exp
+
+
+# ---- the live oracle on many columns: reference library (oracle/_ref) if it travelled, else the C restatement ----------
+def _live_oracle_worker(args):
+    """One host process (the reference Fortran keeps process-global state): SW and LW of one column chunk."""
+    chunk, mcica = args
+    sys.path.insert(0, ROOT)
+    from oracle import ref_driver
+    if ref_driver.available("sw") and ref_driver.available("lw"):
+        from tools.pack_tables import read_blob
+        from tools.synth_lw_tables import fill_reference_from_blob
+        rsw = ref_driver.RefSW()
+        blob = read_blob(LW_DATA)
+        rlw = ref_driver.RefLW(); rlw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+        sw, lw = rsw.fluxes(chunk, mcica=mcica), rlw.fluxes(chunk, mcica=mcica)
+        kind = "reference"
+    else:
+        from oracle.port_driver import PortLW, PortSW
+        sw, lw = PortSW().fluxes(chunk, mcica=mcica), PortLW().fluxes(chunk, mcica=mcica)
+        kind = "port"
+    return ({k: sw[k] for k, _ in SW_OUT}, {k: lw[k] for k, _ in LW_OUT}, kind)
+
+
+def live_oracle(c, mcica, chunk=128, procs=None):
+    """SW and LW outputs of the oracle for the columns of `c` (kissvec or clear sky: columns are independent), computed in
+    column chunks on a pool of host processes -> (sw dict, lw dict, 'reference' | 'port')."""
+    import multiprocessing as mp
+    from climt_amd.distributed import slice_columns
+    ncol = c["play"].shape[1]
+    c = {k: v for k, v in c.items() if k != "lat"}
+    jobs = [(slice_columns(c, s, min(ncol, s + chunk)), mcica) for s in range(0, ncol, chunk)]
+    procs = procs or max(1, min(len(jobs), os.cpu_count() or 1, 32))
+    with mp.get_context("spawn").Pool(procs) as pool:
+        parts = pool.map(_live_oracle_worker, jobs)
+    sw = {k: np.concatenate([p[0][k] for p in parts], axis=1) for k, _ in SW_OUT}
+    lw = {k: np.concatenate([p[1][k] for p in parts], axis=1) for k, _ in LW_OUT}
+    return sw, lw, parts[0][2]

@@ -1,6 +1,8 @@
 """N>1 path on CPU: two processes (torch.distributed, gloo, 127.0.0.1) shard the columns, compute their block
-with the host emulation of the device functions, all-gather the outputs, and must reproduce the unsharded
-result bit for bit -- what the 8-GPU run relies on."""
+with the host emulation of the device functions, gather the outputs, and must reproduce the unsharded
+result bit for bit -- what the 8-GPU run relies on.  The product class under test is
+climt_amd.distributed.ShardedRadiation (flat double-buffered output buffer, gather modes all / root / none);
+on the GPU its communicator is RcclComm (librccl through ctypes), here TorchComm (gloo) on host memory."""
 import os
 import socket
 import sys
@@ -15,20 +17,40 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
+def _cases():
+    """(name, inputs, mcica): kissvec maximum-random, and the Mersenne twister (ONE global stream over (sub-column,
+    column, layer): sharding needs the skip-ahead of rrtmg_mt.cpp) with maximum and maximum-random overlap."""
+    c1, m1, _ = load_ref_case("mcica_kiss_maxrand")
+    c2, m2, _ = load_ref_case("mcica_mt_max")
+    c3 = dict(c2); c3.update(icld=2, permuteseed=12345)
+    return [("kiss_maxrand", c1, m1), ("mt_max", c2, m2), ("mt_maxrand", c3, True)]
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from climt_amd.distributed import sharded_fluxes
-    from helpers import EmuContext, load_ref_case
+    from climt_amd.distributed import ShardedRadiation, TorchComm, sharded_fluxes
+    from helpers import EmuContext
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    c, mcica, _ = load_ref_case("mcica_kiss_maxrand")
     ctx = EmuContext()
-    sw = sharded_fluxes(ctx, c, "sw", mcica, dist, world, rank)
-    lw = sharded_fluxes(ctx, c, "lw", mcica, dist, world, rank)
+    res = {}
+    for name, c, mcica in _cases():
+        c = {k: v for k, v in c.items() if k != "lat"}
+        res[name] = (sharded_fluxes(ctx, c, "sw", mcica, dist, world, rank), sharded_fluxes(ctx, c, "lw", mcica, dist, world, rank))
+    # the product class: three steps (both halves of the double buffer are reused), every gather mode
+    name, c, mcica = _cases()[0]
+    nlay, ncol = c["play"].shape
+    for mode in ("all", "root", "none"):
+        sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, nlay, gather=mode, device=False)
+        sr.set_inputs(c)
+        for _ in range(3):
+            b = sr.step(mcica=mcica)
+        sr.finish()
+        res["sr_" + mode] = (sr.gathered_host(b), (sr.lo, sr.hi))
     dist.barrier()
     dist.destroy_process_group()
-    q.put((rank, sw, lw))
+    q.put((rank, res))
 
 
 def test_two_rank_sharding_is_bit_identical():
@@ -39,18 +61,72 @@ def test_two_rank_sharding_is_bit_identical():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
+    res = dict(q.get(timeout=600) for _ in procs)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    c, mcica, _ = load_ref_case("mcica_kiss_maxrand")
     e = EmuContext()
-    sw0, lw0 = e.sw_fluxes(c, mcica=mcica), e.lw_fluxes(c, mcica=mcica)
-    for rank, sw, lw in res:
-        for k in sw0:
-            assert np.array_equal(sw[k], sw0[k]), (rank, k)
-        for k in lw0:
-            assert np.array_equal(lw[k], lw0[k]), (rank, k)
+    whole = {}
+    for name, c, mcica in _cases():
+        sw0, lw0 = e.sw_fluxes(c, mcica=mcica), e.lw_fluxes(c, mcica=mcica)
+        whole[name] = (sw0, lw0)
+        for rank in (0, 1):
+            sw, lw = res[rank][name]
+            for k in sw0:
+                assert np.array_equal(sw[k], sw0[k]), (name, rank, k)
+            for k in lw0:
+                assert np.array_equal(lw[k], lw0[k]), (name, rank, k)
+    sw0, lw0 = whole["kiss_maxrand"]
+    full = dict(sw0); full.update(lw0)
+    for rank in (0, 1):
+        got, _ = res[rank]["sr_all"]
+        assert set(got) == set(full)
+        assert all(np.array_equal(got[k], full[k]) for k in full), rank
+        got, (lo, hi) = res[rank]["sr_none"]
+        assert all(np.array_equal(got[k], full[k][:, lo:hi]) for k in full), rank
+        got, _ = res[rank]["sr_root"]
+        if rank == 0:
+            assert all(np.array_equal(got[k], full[k]) for k in full)
+        else:
+            assert got is None
+
+
+def test_mersenne_twister_shards_differ_without_the_skip_ahead():
+    """The defect the skip-ahead repairs: a shard that restarts the global stream gets other bits (and correlated draws)."""
+    from climt_amd.distributed import slice_columns
+    c, mcica, _ = load_ref_case("mcica_mt_max")
+    c = {k: v for k, v in c.items() if k != "lat"}
+    e = EmuContext()
+    whole = e.sw_fluxes(c, mcica=True)
+    ncol = c["play"].shape[1]
+    sub = slice_columns(c, 10, ncol)
+    naive = e.sw_fluxes(sub, mcica=True)
+    assert not np.array_equal(naive["swdflx"], whole["swdflx"][:, 10:])
+    sub.update(shard_col0=10, shard_ncol=ncol)
+    right = e.sw_fluxes(sub, mcica=True)
+    assert all(np.array_equal(right[k], whole[k][:, 10:]) for k in whole)
+
+
+def test_slice_columns_uses_the_axis_map_not_shapes():
+    """Column counts equal to a band count (14, 16), to the aerosol-type count (6) or to len(indsolvar) (2) must not
+    change which axis is cut."""
+    from climt_amd.distributed import slice_columns
+    for ncol in (2, 6, 14, 16):
+        nlay = ncol                       # square arrays too
+        inp = dict(play=np.arange(nlay * ncol, dtype=float).reshape(nlay, ncol), tsfc=np.arange(ncol, dtype=float),
+                   emis=np.arange(16 * ncol, dtype=float).reshape(16, ncol),
+                   taucld=np.arange(nlay * ncol * 14, dtype=float).reshape(nlay, ncol, 14),
+                   tauaer=np.arange(14 * nlay * ncol, dtype=float).reshape(14, nlay, ncol),
+                   ecaer=np.arange(6 * nlay * ncol, dtype=float).reshape(6, nlay, ncol),
+                   bndsolvar=np.arange(16, dtype=float), indsolvar=np.arange(2, dtype=float), icld=1)
+        out = slice_columns(inp, 1, 2)
+        assert out["play"].shape == (nlay, 1) and np.array_equal(out["play"][:, 0], inp["play"][:, 1])
+        assert out["tsfc"].shape == (1,) and out["emis"].shape == (16, 1)
+        assert out["taucld"].shape == (nlay, 1, 14) and np.array_equal(out["taucld"][:, 0, :], inp["taucld"][:, 1, :])
+        assert out["tauaer"].shape == (14, nlay, 1) and out["ecaer"].shape == (6, nlay, 1)
+        assert out["bndsolvar"].shape == (16,) and out["indsolvar"].shape == (2,) and out["icld"] == 1
+    with pytest.raises(KeyError):
+        slice_columns(dict(mystery=np.zeros((3, 3))), 0, 1)
 
 
 def test_column_blocks_cover_and_balance():
@@ -62,3 +138,26 @@ def test_column_blocks_cover_and_balance():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [hi - lo for lo, hi in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_tcp_rendezvous_hands_out_rank0s_bytes():
+    """The torch-free exchange of the RCCL unique id (128 arbitrary bytes, NULs included)."""
+    import multiprocessing as mp
+    from climt_amd.distributed import tcp_broadcast
+    port = _free_port()
+    payload = bytes(range(128))[::-1] + b"\x00" * 0
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, 3, port, payload, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=60) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(g == payload for g in got)
+
+
+def _rdzv_worker(rank, world, port, payload, q):
+    sys.path.insert(0, ROOT)
+    from climt_amd.distributed import tcp_broadcast
+    q.put(tcp_broadcast(payload if rank == 0 else b"", rank, world, addr="127.0.0.1", port=port))
