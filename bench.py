@@ -1,21 +1,28 @@
 #!/usr/bin/env python3
 """bench.py -- RRTMG LW+SW columns/s on MI355X (BASELINE.json metric).
 
-A "step" is one pass of the hot path -- shortwave + longwave fluxes and heating rates -- over one batch of
-synthetic columns that is already resident in HBM.  Workload at N=1: BASELINE.json configs[1], clear-sky
-128x64 columns x 60 levels (`--cloudy` switches to configs[2]: McICA liquid+ice clouds, kissvec).
-Columns shard embarrassingly: every rank owns `--columns` columns (weak scaling); for N>1 the 12 output
-arrays are reassembled on every rank with one RCCL all-gather per step (north_star), which is inside the
-timed region.  torch is used ONLY for torch.distributed (launch contract + RCCL); the compute path is
-librrtmg_hip.so through ctypes.
+A "step" is one pass of the hot path -- shortwave + longwave fluxes and heating rates -- over one batch of synthetic
+columns that is already resident in HBM.  Workload (per GPU; columns shard embarrassingly, weak scaling):
+
+    default      BASELINE.json configs[1]: clear sky, 128x64 columns x 60 levels
+    --cloudy     configs[2]: McICA liquid+ice clouds (kissvec), 128x64 x 60
+    --config 4   configs[3]'s per-GPU shard: 16 384 columns x 60 levels, McICA  (8 GPUs = 512x256x60)
+    --config 5   configs[4]'s per-GPU shard: 129 600 columns x 100 levels, McICA (8 GPUs = 1440x720x100)
+
+For N>1 the output arrays are reassembled with RCCL (north_star): climt_amd.distributed.ShardedRadiation, librccl bound
+through ctypes, all-gather of one flat double-buffered device buffer on its own stream (`--gather all|root|none`); the
+gather is inside the timed region.  torch is used ONLY for the launch contract (process group, barrier, max over ranks) and
+as a fallback communicator if librccl cannot be initialised; the compute path is librrtmg_hip.so through ctypes.
 
 Prints ONE JSON line on rank 0 (see the driver contract), with
-  roofline     : dominant kernel = the longer of sw_solve_all_kernel / lw_solve_all_kernel, duration from HIP
-                 events recorded on the library's stream around that launch (rrtmg_hip_kernel_ms);
-                 achieved = algorithmic bytes of that half (SW (34L+11)*8 B, LW (56L+22)*8 B per column,
-                 SURVEY.md 8d) x columns per launch / duration, peak = 8 TB/s HBM3E.
-  cpu_baseline : the reference Fortran (oracle/_ref; LW on the synthetic k-tables) timed on the host cores of
-                 this box on a bounded sample of the same columns (rank 0, N=1 only).
+  roofline     : dominant kernel = the longer of the SW / LW solve kernels, duration from HIP events recorded on the library's
+                 stream around that launch (rrtmg_hip_kernel_ms); achieved = algorithmic bytes of that half (SW (34L+11)*8 B,
+                 LW (56L+22)*8 B per column) x columns per launch / duration, peak = 8 TB/s HBM3E;
+                 traffic / fp64_frac from the PMC passes committed under profiles/ (same command).
+  cpu_baseline : the reference Fortran (oracle/_ref; LW on the synthetic k-tables) timed on the host cores of this box on a
+                 bounded sample of the same columns (rank 0, N=1 only).
+  extra        : (N=1) the McICA configuration in the same run, and the end-to-end rates that include PCIe: the host-pointer
+                 C-ABI and the drop-in component classes on a sympl-style state.
 """
 import argparse
 import json
@@ -32,6 +39,8 @@ CONSTANTS = dict(pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852
                  avogad=6.022140857e23, alosmt=2.6867774e19, gascon=8.3144598e7, sbcnst=5.670367e-12, secdy=86400.0)
 CPDAIR = 1004.64
 HBM_PEAK = 8.0e12
+FP64_PEAK = 78.6e12     # vector FP64, MI355X_MICROARCH.md
+FLAGS = dict(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
 
 
 def _cpu_worker(args):
@@ -41,7 +50,7 @@ def _cpu_worker(args):
     sys.path.insert(0, ROOT)
     from climt_amd.synthetic import make_columns
     c = make_columns(ncol, nlay, cloudy=cloudy, seed=seed)
-    c.update(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
+    c.update(FLAGS)
     if kind == "reference":
         from oracle.ref_driver import RefLW, RefSW
         from tools.pack_tables import read_blob
@@ -49,15 +58,11 @@ def _cpu_worker(args):
         sw = RefSW(); sw.init()
         blob = read_blob(os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin"))
         lw = RefLW(); lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
-        t0 = _t.perf_counter()
-        for _ in range(reps):      # the reference keeps (ngpt, ncol, nlay) automatics on the stack: chunks of `ncol`
-            sw.fluxes(c, mcica=cloudy)
-            lw.fluxes(c, mcica=cloudy)
-        return _t.perf_counter() - t0
-    from oracle.port_driver import PortLW, PortSW   # C restatement
-    sw, lw = PortSW(), PortLW()
+    else:
+        from oracle.port_driver import PortLW, PortSW   # C restatement
+        sw, lw = PortSW(), PortLW()
     t0 = _t.perf_counter()
-    for _ in range(reps):
+    for _ in range(reps):      # the reference keeps (ngpt, ncol, nlay) automatics on the stack: chunks of `ncol`
         sw.fluxes(c, mcica=cloudy)
         lw.fluxes(c, mcica=cloudy)
     return _t.perf_counter() - t0
@@ -73,15 +78,14 @@ def cpu_baseline(nlay, cloudy):
         kind = "port"
     cores = max(1, min(os.cpu_count() or 1, 16))
     per = 256 if not cloudy else 96
-    reps = 96 if not cloudy else 48      # ~10-20 s of CPU work per process
+    reps = int((96 if not cloudy else 48) * 60 / nlay) or 1      # ~10-20 s of CPU work per process
     try:
         ctx = mp.get_context("spawn")
         with ctx.Pool(cores) as pool:
             t0 = time.perf_counter()
             times = pool.map(_cpu_worker, [(kind, per, nlay, cloudy, 1000 + i, reps) for i in range(cores)])
             wall = time.perf_counter() - t0
-        # throughput of the timed compute regions running concurrently on `cores` processes
-        v = cores * per * reps / max(times)
+        v = cores * per * reps / max(times)      # the timed compute regions run concurrently on `cores` processes
         return {"value": v, "unit": "columns/s", "cores": cores, "kind": kind,
                 "sample": "%d processes x %d calls x %d synthetic columns x %d levels, LW+SW %s; compute region max %.2f s (pool wall %.1f s); "
                           "LW on synthetic k-tables" % (cores, reps, per, nlay, "McICA" if cloudy else "clear-sky", max(times), wall)}
@@ -89,27 +93,95 @@ def cpu_baseline(nlay, cloudy):
         return {"value": None, "unit": "columns/s", "cores": 0, "kind": kind, "sample": "cpu baseline failed: %r" % (e,)}
 
 
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
+    except Exception:
+        return {}
+
+
+class _TorchBuf:
+    """A device buffer owned by torch (fallback communicator): the same .ptr / .download() as _hip.DeviceArray."""
+
+    def __init__(self, shape, device):
+        import torch
+        self.t = torch.empty(int(np.prod(shape)), dtype=torch.float64, device=device)
+        self.ptr = self.t.data_ptr()
+
+    def download(self):
+        return self.t.cpu().numpy()
+
+
+class _TorchDeviceComm:
+    """Fallback for N>1 when librccl cannot be initialised directly: torch.distributed (backend nccl = RCCL) on buffers
+    that torch allocated; same interface as climt_amd.distributed.RcclComm."""
+
+    def __init__(self, dist, rank, world, device):
+        import torch
+        self.dist, self.rank, self.world, self.device = dist, rank, world, device
+        self.bufs, self.work = {}, []
+        self.kind = "torch." + dist.get_backend()
+
+        class _S:      # the library's kernels are waited for on the host in this fallback (no foreign stream handle)
+            s = None
+        self.stream = _S()
+        self.torch = torch
+
+    def alloc(self, shape):
+        b = _TorchBuf(shape, self.device)
+        self.bufs[b.ptr] = b.t
+        return b
+
+    def all_gather(self, send_ptr, recv_ptr, count):
+        self.work.append(self.dist.all_gather_into_tensor(self.bufs[recv_ptr], self.bufs[send_ptr][:count], async_op=True))
+
+    def gather_root(self, send_ptr, recv_ptr, count):
+        if self.rank == 0:
+            parts = list(self.bufs[recv_ptr].view(self.world, count).unbind(0))
+            self.work.append(self.dist.gather(self.bufs[send_ptr][:count], parts, dst=0, async_op=True))
+        else:
+            self.work.append(self.dist.gather(self.bufs[send_ptr][:count], None, dst=0, async_op=True))
+
+    def wait(self):
+        for w in self.work:
+            w.wait()
+        self.work = []
+        self.torch.cuda.synchronize()
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--columns", type=int, default=128 * 64, help="columns per GPU")
-    ap.add_argument("--levels", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: enough for >= 1 s of timed region)")
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 3, 4, 5], help="BASELINE.json configs[] index + 1 (2 clear, 3 McICA, 4 / 5 the 8-GPU grids' per-GPU shard)")
+    ap.add_argument("--columns", type=int, default=None, help="columns per GPU (overrides the preset)")
+    ap.add_argument("--levels", type=int, default=None)
     ap.add_argument("--cloudy", action="store_true", help="configs[2]: McICA liquid+ice clouds (kissvec)")
-    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL output all-gather (N>1)")
+    ap.add_argument("--gather", default="all", choices=["all", "root", "none"], help="N>1: what happens to the outputs (RCCL)")
+    ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the McICA / end-to-end extras (N=1)")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to exercise the N>1 logic)")
-    ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (with --dist-backend gloo)")
-    ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (process group, output all-gather) with a single rank too")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default) or torch.distributed")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
+    ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (communicator, gather) with a single rank too")
     a = ap.parse_args()
+    preset = {2: (8192, 60, False), 3: (8192, 60, True), 4: (16384, 60, True), 5: (129600, 100, True)}[a.config]
+    N = a.columns or preset[0]
+    L = a.levels or preset[1]
+    cloudy = a.cloudy or preset[2]
+    if a.no_gather:
+        a.gather = "none"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = 0 if a.share_device else int(os.environ.get("LOCAL_RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or a.force_dist
-    if world != a.gpus and world > 1:
+    if world > 1:
         a.gpus = world
     dist = None
     if multi:
@@ -129,159 +201,217 @@ def main():
     ctx.set_constants(**CONSTANTS)
     ctx.sw_init(CPDAIR)
     ctx.lw_init(CPDAIR)
-    N, L = a.columns, a.levels
-    c = make_columns(N, L, cloudy=a.cloudy, seed=20260927 + rank)
-    c.update(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
-    dev = {k: _hip.DeviceArray.from_host(v) for k, v in c.items() if isinstance(v, np.ndarray) and k != "lat"}
-    inp = {k: v.ptr for k, v in dev.items()}
-    inp.update({k: v for k, v in c.items() if not isinstance(v, np.ndarray)})
-    inp.update(ncol=N, nlay=L)
 
-    # outputs: one flat device buffer holding the 12 arrays (so that one all-gather moves them all)
-    sizes = [(k, (L + lev) * N) for k, lev in SW_OUT] + [(k, (L + lev) * N) for k, lev in LW_OUT]
-    total = sum(s for _, s in sizes)
-    # Two output buffers (N>1): the RCCL all-gather of step i runs while step i+1 computes into the other one.
-    nbuf = 2 if multi else 1
-    if multi:
-        import torch
-        flats = [torch.empty(total, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
-        gathered = [torch.empty(total * world, dtype=torch.float64, device="cuda:%d" % local) for _ in range(nbuf)]
-        bases = [f.data_ptr() for f in flats]
-    else:
-        flats = [_hip.DeviceArray((total,))]
-        bases = [flats[0].ptr]
-    outs = []
-    for base in bases:
+    def columns(ncol, nlay, cld):
+        c = make_columns(ncol, nlay, cloudy=cld, seed=20260927 + rank)
+        c.update(FLAGS)
+        c.pop("lat")
+        return c
+
+    def resident(c):
+        dev = {k: _hip.DeviceArray.from_host(v) for k, v in c.items() if isinstance(v, np.ndarray)}
+        inp = {k: v.ptr for k, v in dev.items()}
+        inp.update({k: v for k, v in c.items() if not isinstance(v, np.ndarray)})
+        inp.update(ncol=c["play"].shape[1], nlay=c["play"].shape[0])
+        return dev, inp
+
+    def device_run(ncol, nlay, cld, steps, warmup, serial):
+        """Single-GPU device-resident loop: -> (ms per step from the whole region, per-step ms list, kernel ms lists)."""
+        c = columns(ncol, nlay, cld)
+        dev, inp = resident(c)
+        sizes = [(k, (nlay + lev) * ncol) for k, lev in SW_OUT] + [(k, (nlay + lev) * ncol) for k, lev in LW_OUT]
+        flat = _hip.DeviceArray((sum(s for _, s in sizes),))
         off, so, lo = 0, {}, {}
         for i, (k, s) in enumerate(sizes):
-            (so if i < 6 else lo)[k] = base + 8 * off
+            (so if i < 6 else lo)[k] = flat.ptr + 8 * off
             off += s
-        outs.append((so, lo))
-    sw_out, lw_out = outs[0]
+        ctx.set_deferred(not serial)
+        enq = [0.0, 0.0]
 
-    # one step = LW+SW of the whole batch, outputs complete (and checked) when it returns.  By default the two
-    # spectra are enqueued in deferred mode on two streams so that they overlap on the GPU.
-    ctx.set_deferred(not a.serial)
+        def step():
+            t = time.perf_counter()
+            ctx.sw_fluxes(inp, mcica=cld, out=so, memspace=1)
+            enq[0] += time.perf_counter() - t
+            ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
+            enq[1] += time.perf_counter() - t
+            ctx.synchronize()
+        for _ in range(warmup):
+            step()
+        _hip.synchronize()
+        enq[0] = enq[1] = 0.0
+        per, ksw, klw = [], [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t = time.perf_counter()
+            step()
+            per.append((time.perf_counter() - t) * 1e3)
+            ksw.append(ctx.kernel_ms("sw", cloudy=cld))
+            klw.append(ctx.kernel_ms("lw", cloudy=cld))
+        _hip.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
+        ctx.set_deferred(False)
+        ssw, slw = [], []
+        for _ in range(3):      # kernel durations without the SW||LW overlap, for reference
+            ctx.sw_fluxes(inp, mcica=cld, out=so, memspace=1)
+            ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
+            ssw.append(ctx.kernel_ms("sw", cloudy=cld))
+            slw.append(ctx.kernel_ms("lw", cloudy=cld))
+        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / steps, enq=enq[1] * 1e3 / steps, c=c)
 
-    state = {"i": 0, "work": None, "ready": None, "enq": 0.0, "enq_sw": 0.0}
+    def pick_steps(ncol, nlay, cld):
+        """Enough steps for >= 1 s of timed region (estimated from the large-grid rates of DESIGN.md 5)."""
+        est = ncol * (nlay / 60.0) / (2.0e6 if cld else 4.0e6)
+        return max(10, int(np.ceil(1.2 / est)))
 
-    def drain():
-        """Wait (host side) for the all-gather in flight, if any: its source buffer may be reused afterwards."""
-        if state["work"] is not None:
-            import torch
-            state["work"].wait()
-            torch.cuda.synchronize()
-            state["work"] = None
+    steps = a.steps if a.steps is not None else pick_steps(N, L, cloudy)
+    warmup = a.warmup if a.warmup is not None else max(2, min(10, steps // 20))
+    comm_note, comm_kind = "", None
 
-    def gather_ready():
-        """Start the all-gather of the buffer whose step is complete but not gathered yet (if any)."""
-        if state["ready"] is not None and not a.no_gather:
-            b = state["ready"]
+    if not multi:
+        r = device_run(N, L, cloudy, steps, warmup, a.serial)
+        ms, per = r["ms"], r["per"]
+    else:
+        import torch
+        from climt_amd.distributed import RcclComm, ShardedRadiation
+        comm = None
+        if a.comm == "rccl" and a.gather != "none":
+            def bcast(payload, rk, wd):      # the unique id travels over the launch contract's process group
+                box = [payload]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
             try:
-                state["work"] = dist.all_gather_into_tensor(gathered[b], flats[b], async_op=True)
-            except Exception as e:      # keep measuring the compute; the JSON line says that the gather did not run
-                a.no_gather, state["gather_error"] = True, "%s: %s" % (type(e).__name__, str(e)[:200])
-        state["ready"] = None
+                comm = RcclComm(rank, world, local, broadcast=bcast)
+            except Exception as e:
+                comm_note = "librccl via ctypes failed (%s: %s); " % (type(e).__name__, str(e)[:160])
+            ok = torch.tensor([1 if comm is not None else 0], device="cuda:%d" % local)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # all ranks or none
+            if int(ok.item()) == 0:
+                comm = None
+        alloc = None
+        if comm is None:
+            comm = _TorchDeviceComm(dist, rank, world, "cuda:%d" % local)
+            alloc = comm.alloc
+        comm_kind = comm.kind
+        sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist)
+        if a.serial:
+            ctx.set_deferred(False)
+        sr.set_inputs(columns(N, L, cloudy), already_local=True)
+        host_wait = comm.kind != "rccl"
 
-    def step():
-        # N>1: the all-gather of step i-1 is started right AFTER step i's kernels are enqueued, so that both its launch
-        # cost on the host and its transfer overlap step i's compute; the gather started during step i-1 read the buffer
-        # this step overwrites, so it is waited for first (it has had a whole step to finish).
-        b = state["i"] % nbuf
-        state["i"] += 1
-        so, lo = outs[b]
-        if multi:
-            drain()
-        t = time.perf_counter()
-        ctx.sw_fluxes(inp, mcica=a.cloudy, out=so, memspace=1)
-        state["enq_sw"] += time.perf_counter() - t
-        ctx.lw_fluxes(inp, mcica=a.cloudy, out=lo, memspace=1)
-        state["enq"] += time.perf_counter() - t
-        if multi:
-            gather_ready()
-        ctx.synchronize()          # this step's outputs are complete and checked
-        if multi:
-            state["ready"] = b
+        def step():
+            b = sr.step(mcica=cloudy, host_wait=host_wait)
+            return b
 
-    def fence():
-        ctx.synchronize()
-        if multi:
-            import torch
-            drain()
-            gather_ready()         # the last step's outputs
-            drain()
+        def fence():
+            sr.finish()
             dist.barrier()
             torch.cuda.synchronize()
-        else:
-            _hip.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    ksw, klw = [], []
-    state["enq"] = state["enq_sw"] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-        ksw.append(ctx.kernel_ms("sw", cloudy=a.cloudy))      # the kernel that does the work in this configuration
-        klw.append(ctx.kernel_ms("lw", cloudy=a.cloudy))
-    fence()
-    ms = (time.perf_counter() - t0) * 1e3 / a.steps
-    if multi:
-        import torch
+        for _ in range(warmup):
+            step()
+        fence()
+        per, ksw, klw = [], [], []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            t = time.perf_counter()
+            step()
+            per.append((time.perf_counter() - t) * 1e3)
+            ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
+            klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
+        fence()
+        ms = (time.perf_counter() - t0) * 1e3 / steps
         t = torch.tensor([ms], dtype=torch.float64, device="cuda:%d" % local)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ms = float(t.item())
+        r = dict(ksw=ksw, klw=klw, ssw=ksw, slw=klw, enq_sw=0.0, enq=0.0)
     value = world * N / (ms * 1e-3)
-    # kernel durations without the SW||LW overlap (3 extra untimed serial steps), for reference
-    ctx.set_deferred(False)
-    ssw, slw = [], []
-    for _ in range(3):
-        ctx.sw_fluxes(inp, mcica=a.cloudy, out=sw_out, memspace=1)
-        ctx.lw_fluxes(inp, mcica=a.cloudy, out=lw_out, memspace=1)
-        ssw.append(ctx.kernel_ms("sw", cloudy=a.cloudy))
-        slw.append(ctx.kernel_ms("lw", cloudy=a.cloudy))
 
+    res = None
     if rank == 0:
-        sw_ms, lw_ms = float(np.mean(ksw)), float(np.mean(klw))
+        sw_ms, lw_ms = float(np.mean(r["ksw"])), float(np.mean(r["klw"]))
         # the cloudy / clear-sky instantiation that does the work (names as rocprofv3 prints them)
         if sw_ms >= lw_ms:
-            kname, kms, bpc = ("rrtmg::sw_solve_cloudy_kernel" if a.cloudy else "rrtmg::sw_solve_all_kernel<false>"), sw_ms, (34 * L + 11) * 8
+            kname, kms, bpc = ("rrtmg::sw_solve_cloudy_kernel" if cloudy else "rrtmg::sw_solve_all_kernel<false>"), sw_ms, (34 * L + 11) * 8
         else:
-            kname, kms, bpc = "rrtmg::lw_solve_all_kernel" + ("<true, false>" if a.cloudy else "<false, false>"), lw_ms, (56 * L + 22) * 8
+            kname, kms, bpc = "rrtmg::lw_solve_all_kernel" + ("<true, false>" if cloudy else "<false, false>"), lw_ms, (56 * L + 22) * 8
         achieved = bpc * N / (kms * 1e-3) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tfile):
-            try:
-                tj = json.load(open(tfile))
-                key = "%s|%d|%d|%s" % (kname, N, L, "cloudy" if a.cloudy else "clear")
-                traffic = tj.get(key)
-            except Exception:
-                traffic = None
+        key = "%s|%d|%d|%s" % (kname, N, L, "cloudy" if cloudy else "clear")
+        traffic = _profile_json("hbm_traffic.json").get(key)
+        flops = _profile_json("fp64_flops.json").get(key)      # FP64 flops per launch from the SQ instruction counters
+        par = "columns sharded x%d" % world
+        if world > 1:
+            par += {"all": " + RCCL all-gather of the outputs (one flat buffer, double-buffered: runs under the next step's kernels)",
+                    "root": " + RCCL gather of the outputs to rank 0 (double-buffered)", "none": ", outputs stay on their GPU"}[a.gather]
         res = {
-            "metric": "LW+SW columns/sec (60 lev)", "value": value, "unit": "columns/s", "n_gpus": world, "steps": a.steps,
-            "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "metric": "LW+SW columns/sec (60 lev)", "value": value, "unit": "columns/s", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "rrtmg_lw+sw_%s_%dcol_x_%dlev_per_gpu" % ("mcica_cloudy" if a.cloudy else "clear_sky", N, L),
-                       "columns_per_gpu": N, "levels": L, "parallelism": "columns sharded x%d%s" % (world, (" (output all-gather FAILED and was switched off: %s)" % state["gather_error"]) if state.get("gather_error") else "" if world == 1 or a.no_gather else " + RCCL all-gather of outputs (double-buffered: overlaps the next step's compute)"),
+            "config": {"workload": "rrtmg_lw+sw_%s_%dcol_x_%dlev_per_gpu" % ("mcica_cloudy" if cloudy else "clear_sky", N, L),
+                       "baseline_config": a.config if not (a.columns or a.levels) else None,
+                       "columns_per_gpu": N, "levels": L, "parallelism": par,
+                       "communicator": (comm_note + comm_kind) if comm_kind else None,
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
+                       "timed_region_s": ms * steps * 1e-3, "ms_per_step_median": float(np.median(per)),
+                       "ms_per_step_p10_p90": [float(np.percentile(per, 10)), float(np.percentile(per, 90))],
                        "lw_k_tables": "synthetic (reference LW data file missing)", "sw_k_tables": "reference"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms,
                          "algorithmic_bytes_per_column": bpc, "sw_solve_ms": sw_ms, "lw_solve_ms": lw_ms,
-                         "sw_solve_ms_serial": float(np.mean(ssw)), "lw_solve_ms_serial": float(np.mean(slw)),
-                         "host_call_ms": {"sw": state["enq_sw"] * 1e3 / a.steps, "sw+lw": state["enq"] * 1e3 / a.steps},
-                         "note": "achieved/frac: algorithmic bytes over the event-timed duration in the timed region (SW and LW kernels overlap there); "
-                                 "`traffic` = measured HBM bytes per launch (PMC): scratch slab + partial-flux planes, ~40 % of HBM peak "
-                                 "at the serial kernel duration"},
+                         "sw_solve_ms_serial": float(np.mean(r["ssw"])), "lw_solve_ms_serial": float(np.mean(r["slw"])),
+                         "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
+                         "host_call_ms": {"sw": r["enq_sw"], "sw+lw": r["enq"]},
+                         "note": "achieved/frac: ALGORITHMIC bytes over the event-timed duration in the timed region (SW and LW kernels overlap "
+                                 "there); `traffic` = measured HBM bytes per launch and `fp64_flops_per_launch` = measured FP64 flops per launch "
+                                 "(PMC passes of this command, profiles/); the path is 108 FLOP/B on algorithmic bytes: FP64-issue / latency "
+                                 "bound, not HBM bound (fp64_frac is the fraction of the 78.6 TF vector peak)"},
         }
-        if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(L, a.cloudy)
-        else:
-            res["cpu_baseline"] = None
-    else:
-        res = None
+        res["cpu_baseline"] = None
+        if world == 1 and not multi:
+            if not a.no_extra:
+                extra = {}
+                # (a) configs[2] in the same run: McICA liquid+ice clouds, kissvec
+                if not cloudy:
+                    st = pick_steps(8192, 60, True) if a.steps is None else max(5, a.steps // 2)
+                    m = device_run(8192, 60, True, st, 3, a.serial)
+                    extra["mcica"] = {"workload": "rrtmg_lw+sw_mcica_cloudy_8192col_x_60lev_per_gpu", "value": 8192 / (m["ms"] * 1e-3), "unit": "columns/s",
+                                      "ms_per_step": m["ms"], "ms_per_step_median": float(np.median(m["per"])), "steps": st,
+                                      "sw_solve_cloudy_ms": float(np.mean(m["ksw"])), "lw_solve_cloudy_ms": float(np.mean(m["klw"])),
+                                      "sw_solve_cloudy_ms_serial": float(np.mean(m["ssw"])), "lw_solve_cloudy_ms_serial": float(np.mean(m["slw"]))}
+                # (b) end to end including PCIe: host-pointer C-ABI (H2D of every input, D2H of the 12 outputs per call)
+                try:
+                    c = r["c"]
+                    n_e = max(3, min(20, int(0.5 / (N * L / 60 / 1.0e6)) or 3))
+                    ctx.sw_fluxes(c, mcica=cloudy); ctx.lw_fluxes(c, mcica=cloudy)
+                    t0 = time.perf_counter()
+                    for _ in range(n_e):
+                        ctx.sw_fluxes(c, mcica=cloudy); ctx.lw_fluxes(c, mcica=cloudy)
+                    e2e = (time.perf_counter() - t0) / n_e
+                    h2d = sum(v.nbytes for v in c.values() if isinstance(v, np.ndarray))
+                    extra["end_to_end_host_pointers"] = {"value": N / e2e, "unit": "columns/s", "ms_per_step": e2e * 1e3, "calls": n_e,
+                                                         "bytes_in_per_step": int(h2d * 2), "bytes_out_per_step": int((12 * L + 8) * 8 * N),
+                                                         "note": "rrtmg_hip_{sw,lw}_fluxes with memspace=0: pageable numpy arrays in, outputs back, synchronous SW then LW"}
+                except Exception as e:   # pragma: no cover
+                    extra["end_to_end_host_pointers"] = {"error": repr(e)[:200]}
+                # (c) the drop-in component classes on a sympl-style state (unit conversion, contiguity, numpy host prep)
+                try:
+                    import climt_amd
+                    sw_c = climt_amd.RRTMGShortwave(mcica=cloudy, random_number_generator="kissvec") if cloudy else climt_amd.RRTMGShortwave()
+                    lw_c = climt_amd.RRTMGLongwave(mcica=cloudy, random_number_generator="kissvec", allow_synthetic_tables=True) if cloudy \
+                        else climt_amd.RRTMGLongwave(allow_synthetic_tables=True)
+                    state = climt_amd.get_default_state([sw_c, lw_c], grid_state=climt_amd.get_grid(nx=128, ny=N // 128, nz=L))
+                    sw_c(state); lw_c(state)
+                    n_c = 5
+                    t0 = time.perf_counter()
+                    for _ in range(n_c):
+                        sw_c(state); lw_c(state)
+                    cls = (time.perf_counter() - t0) / n_c
+                    extra["end_to_end_components"] = {"value": 128 * (N // 128) / cls, "unit": "columns/s", "ms_per_step": cls * 1e3, "calls": n_c,
+                                                      "note": "RRTMGShortwave()(state) + RRTMGLongwave()(state) on get_default_state(128 x %d x %d): "
+                                                              "sympl-style DataArrays in, tendencies + diagnostics out" % (N // 128, L)}
+                except Exception as e:   # pragma: no cover
+                    extra["end_to_end_components"] = {"error": repr(e)[:200]}
+                res["extra"] = extra
+            if not a.no_cpu_baseline:
+                res["cpu_baseline"] = cpu_baseline(L, cloudy)
     # The JSON line must be the LAST line on stdout: RCCL (NCCL_DEBUG=VERSION) writes its banner through C stdio, which
     # would otherwise be flushed after it at exit.  Everyone flushes C stdio, the ranks meet, then rank 0 prints.
     if multi:
@@ -289,6 +419,10 @@ def main():
         sys.stdout.flush()
         ctypes.CDLL(None).fflush(None)
         dist.barrier()
+        try:
+            comm.close()
+        except Exception:
+            pass
         dist.destroy_process_group()
         ctypes.CDLL(None).fflush(None)
     if res is not None:

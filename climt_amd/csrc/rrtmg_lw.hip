@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   const double *sh_k = nullptr;
 #else
   constexpr bool kLdsK = true;
-  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * 4];   // rows are read 16 bytes at a time
+  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * RRTMG_LW_GMAX];   // rows are read 16 bytes at a time
   {
     const LwBandTab &B = T.b[item & 0xff];
     const double *src = T.t + B.slab + ig0;

@@ -156,11 +156,24 @@ constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
 #ifndef RRTMG_SWC_WAVES
 #define RRTMG_SWC_WAVES 3
 #endif
+#ifndef RRTMG_SWC_XCD
+#define RRTMG_SWC_XCD 0
+#endif
 __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   // launch order: tile groups, within a group the items heaviest first -- the group's prep rows (12 tiles x 0.46 MB) are
   // fetched while its 56 items run, instead of the whole prep slab once per item
   const int q = blockIdx.x;
+#if RRTMG_SWC_XCD
+  // XCD-aware order (speed only): block q is observed to run on XCD q % 8, each XCD with its own 4 MB L2.  Tile group g is
+  // given to XCD g % 8 and its items run there one after the other, so the group's prep rows are fetched into ONE L2 and
+  // shared by the items in flight, instead of being fetched by all eight.
+  const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
+  const int grp = ((q >> 3) / T.nitem[1]) * 8 + (q & 7), k = (q >> 3) % T.nitem[1];
+  if (grp >= ngrp) return;
+  const int ctile0 = grp * kSwCldWgWaves;
+#else
   const int ctile0 = (q / T.nitem[1]) * kSwCldWgWaves, k = q % T.nitem[1];
+#endif
   {
     bool mine = false;
     for (int w = 0; w < kSwCldWgWaves; ++w)
@@ -414,7 +427,9 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     if (last) (void)hipEventRecord(ctx->ev[0][1], s);
     if (clouds) {
       if (last) (void)hipEventRecord(ctx->ev[2][0], s);
-      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kSwCldWgWaves - 1) / kSwCldWgWaves * T.nitem[1]), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
+      const int cgrp = (nt + kSwCldWgWaves - 1) / kSwCldWgWaves;
+      const int cgrid = (RRTMG_SWC_XCD ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
       if (last) (void)hipEventRecord(ctx->ev[2][1], s);
     }
     hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);

@@ -232,7 +232,7 @@ class ShardedRadiation:
     `ctx` is a climt_amd._lib.Context (device memory) -- or the tests' host emulation, in which case the buffers are numpy.
     """
 
-    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2):
+    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2, allocator=None, force=False):
         if gather not in ("all", "root", "none"):
             raise ValueError("gather must be 'all', 'root' or 'none'")
         self.ctx, self.comm, self.gather, self.device = ctx, comm, gather, device
@@ -245,18 +245,20 @@ class ShardedRadiation:
         self.levs = [lev for _, lev in SW_OUT] + [lev for _, lev in LW_OUT] + ([1, 1] if idrv else [])
         self.idrv = idrv
         self.block = sum((nlay + lev) * self.width for lev in self.levs)       # doubles per rank in the gathered buffer
-        self.nbuf = nbuf if self.world > 1 and gather != "none" else 1
-        gathered_here = gather == "all" or (gather == "root" and self.rank == 0)
+        self.do_gather = gather != "none" and (self.world > 1 or force)     # force: run the collective with one rank too (tests)
+        self.nbuf = nbuf if self.do_gather else 1
+        gathered_here = self.do_gather and (gather == "all" or (gather == "root" and self.rank == 0))
         if device:
             from . import _hip
             self._hip = _hip
-            self.flat = [_hip.DeviceArray((self.block,)) for _ in range(self.nbuf)]
-            self.full = [_hip.DeviceArray((self.block * self.world,)) if gathered_here and self.world > 1 else None for _ in range(self.nbuf)]
+            alloc = allocator or (lambda shape: _hip.DeviceArray(shape))     # (a communicator may need to own the buffers)
+            self.flat = [alloc((self.block,)) for _ in range(self.nbuf)]
+            self.full = [alloc((self.block * self.world,)) if gathered_here else None for _ in range(self.nbuf)]
             self.events = [_hip.Event() for _ in range(self.nbuf)]
             ctx.set_deferred(True)
         else:
             self.flat = [np.zeros(self.block) for _ in range(self.nbuf)]
-            self.full = [np.zeros(self.block * self.world) if gathered_here and self.world > 1 else None for _ in range(self.nbuf)]
+            self.full = [np.zeros(self.block * self.world) if gathered_here else None for _ in range(self.nbuf)]
         self.inflight = [False] * self.nbuf
         self.i = 0
         self.inp = None
@@ -294,20 +296,26 @@ class ShardedRadiation:
         lw = {k: o[k] for k in self.names[len(SW_OUT):]}
         return sw, lw
 
-    def step(self, mcica=False):
-        """One LW+SW pass over this rank's block into buffer b = step number mod nbuf; starts its gather; returns b."""
+    def step(self, mcica=False, host_wait=False):
+        """One LW+SW pass over this rank's block into buffer b = step number mod nbuf; starts its gather; returns b.
+        host_wait: the communicator cannot be ordered after the kernels on the device (no stream of its own): the host
+        waits for the kernels before it starts the gather."""
         b = self.i % self.nbuf
         self.i += 1
         if self.inflight[b]:                      # the gather that read this buffer (nbuf steps ago) must be done
-            if self.device:
+            if self.device and getattr(self, "_host_wait", False):
+                self.comm.wait()
+            elif self.device:
                 self.events[b].synchronize()
             self.inflight[b] = False
         sw, lw = self._out(b)
         ms = 1 if self.device else 0
         self.ctx.sw_fluxes(self.inp, mcica=mcica, out=sw, memspace=ms)
         self.ctx.lw_fluxes(self.inp, mcica=mcica, out=lw, memspace=ms)
-        if self.world > 1 and self.gather != "none":
-            if self.device:
+        if self.do_gather:
+            if self.device and host_wait:
+                self.ctx.synchronize()
+            elif self.device:
                 self.ctx.stream_wait(self.comm.stream.s)      # device-side: the gather starts when the kernels are done
             send = self.flat[b].ptr if self.device else self.flat[b]
             recv = (self.full[b].ptr if self.device else self.full[b]) if self.full[b] is not None else None
@@ -315,9 +323,10 @@ class ShardedRadiation:
                 self.comm.all_gather(send, recv, self.block)
             else:
                 self.comm.gather_root(send, recv if recv is not None else 0, self.block)
-            if self.device:
+            if self.device and not host_wait:
                 self.events[b].record(self.comm.stream.s)
             self.inflight[b] = True
+            self._host_wait = host_wait
         if self.device:
             self.ctx.synchronize()                # this step's kernels are complete and their status checked
         return b
@@ -326,7 +335,7 @@ class ShardedRadiation:
         """Wait for every gather in flight."""
         for b in range(self.nbuf):
             if self.inflight[b]:
-                if self.device:
+                if self.device and not getattr(self, "_host_wait", False):
                     self.events[b].synchronize()
                 self.inflight[b] = False
         self.comm.wait()
@@ -338,7 +347,7 @@ class ShardedRadiation:
 
     def gathered_host(self, b):
         """The full-grid outputs of buffer b as numpy arrays (ranks that hold them: all, or rank 0 with gather='root')."""
-        if self.world == 1 or self.gather == "none":
+        if not self.do_gather:
             return self.local_host(b)
         if self.full[b] is None:
             return None

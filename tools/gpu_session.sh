@@ -1,0 +1,79 @@
+#!/bin/bash
+# One gpurun session (development tool): tools/gpu_session.sh <tag> <sections...>
+#   sections: tests bench dist sizes ab:<lib1,lib2,...> prof pmc pmclarge sq
+# Everything lands under gpurun_out/<tag>_*; the summaries to be judged are copied into profiles/ afterwards.
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+export RRTMG_HIP_ALLOW_SYNTHETIC_LW=1
+R=$1; shift
+O=gpurun_out
+mkdir -p $O
+stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py $f > $2; }
+pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f _solve_ > $2; }
+for sec in "$@"; do
+  echo "=== section $sec ($(date +%T))"
+  case $sec in
+    tests)
+      timeout 1500 python -m pytest tests -m gpu -q -x --durations=15 > $O/${R}_pytest.log 2>&1; echo "pytest rc=$?" >> $O/${R}_pytest.log; tail -25 $O/${R}_pytest.log ;;
+    smoke)
+      timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3 ;;
+    bench)
+      timeout 600 python bench.py > $O/${R}_bench_default.log 2>&1; grep "^{" $O/${R}_bench_default.log | tail -1 > $O/${R}_bench_default.json; cut -c1-600 $O/${R}_bench_default.json
+      timeout 600 python bench.py --cloudy > $O/${R}_bench_default_cloudy.log 2>&1; grep "^{" $O/${R}_bench_default_cloudy.log | tail -1 > $O/${R}_bench_default_cloudy.json; cut -c1-400 $O/${R}_bench_default_cloudy.json ;;
+    dist)
+      for g in all root none; do
+        timeout 300 python bench.py --force-dist --gather $g --no-cpu-baseline --no-extra --steps 100 > $O/${R}_dist_$g.log 2>&1; echo "dist $g rc=$?"; grep "^{" $O/${R}_dist_$g.log | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['value']), j['ms_per_step'], j['config']['communicator'], j['config']['parallelism'][:60])" || tail -5 $O/${R}_dist_$g.log
+      done
+      timeout 300 python bench.py --force-dist --comm torch --no-cpu-baseline --no-extra --steps 100 > $O/${R}_dist_torch.log 2>&1; grep "^{" $O/${R}_dist_torch.log | tail -1 | cut -c1-200 ;;
+    sizes)
+      for c in 4 5; do
+        timeout 600 python bench.py --config $c --no-cpu-baseline --no-extra > $O/${R}_bench_config$c.log 2>&1; grep "^{" $O/${R}_bench_config$c.log | tail -1 > $O/${R}_bench_config$c.json; cut -c1-300 $O/${R}_bench_config$c.json
+      done
+      timeout 600 python bench.py --columns 131072 --no-cpu-baseline --no-extra > $O/${R}_bench_clear131072.log 2>&1; grep "^{" $O/${R}_bench_clear131072.log | tail -1 > $O/${R}_bench_clear131072.json; cut -c1-300 $O/${R}_bench_clear131072.json ;;
+    ab:*)
+      for lib in $(echo ${sec#ab:} | tr , ' '); do
+        for mode in "" "--cloudy"; do
+          L=$PWD/climt_amd/_lib/$lib; [ $lib = product ] && L=$PWD/climt_amd/_lib/librrtmg_hip.so
+          RRTMG_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 150 $mode 2>&1 | tail -1 | python -c "
+import json,sys
+try:
+    j=json.loads(sys.stdin.read()); r=j['roofline']
+    print('%-14s %-8s %9d col/s %7.3f ms (median %.3f)  sw %.3f lw %.3f | serial sw %.3f lw %.3f' % ('$lib', '$mode', j['value'], j['ms_per_step'], j['config']['ms_per_step_median'], r['sw_solve_ms'], r['lw_solve_ms'], r['sw_solve_ms_serial'], r['lw_solve_ms_serial']))
+except Exception as e:
+    print('$lib $mode FAILED', e)" | tee -a $O/${R}_ab.txt
+        done
+      done ;;
+    prof)
+      for mode in clear cloudy; do
+        flag=""; [ $mode = cloudy ] && flag="--cloudy"
+        for variant in overlap serial; do
+          vf=""; [ $variant = serial ] && vf="--serial"
+          out=$O/prof_${mode}_$variant; rm -rf $out
+          timeout 240 rocprofv3 --kernel-trace --stats -d $out -- python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 3 $flag $vf > $out.log 2>&1
+          grep "^{" $out.log | tail -1 > $O/${R}_bench_${mode}_$variant.json
+          stats $out $O/${R}_bench_${mode}_${variant}_kernel_stats.txt
+        done
+      done; head -12 $O/${R}_bench_clear_serial_kernel_stats.txt ;;
+    pmc|pmclarge)
+      n=8192; tag=""; [ $sec = pmclarge ] && { n=131072; tag="_131072"; }
+      for mode in clear cloudy; do
+        flag=""; [ $mode = cloudy ] && flag="--cloudy"
+        for c in FETCH_SIZE WRITE_SIZE; do
+          out=$O/pmc_${mode}_$c$tag; rm -rf $out
+          timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out -- python bench.py --columns $n --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 $flag > $out.log 2>&1
+          pmc $out $O/${R}_pmc_${mode}_$c$tag.txt; cat $O/${R}_pmc_${mode}_$c$tag.txt
+        done
+      done ;;
+    sq)
+      for mode in clear cloudy; do
+        flag=""; [ $mode = cloudy ] && flag="--cloudy"
+        i=0
+        for P in "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
+          i=$((i+1)); out=$O/sq_${mode}_$i; rm -rf $out
+          timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 $flag > $out.log 2>&1
+          pmc $out $O/${R}_sq_${mode}_$i.txt
+        done
+        cat $O/${R}_sq_${mode}_1.txt $O/${R}_sq_${mode}_2.txt > $O/${R}_pmc_${mode}_sq.txt
+      done; cat $O/${R}_pmc_clear_sq.txt ;;
+  esac
+done
+echo "=== done ($(date +%T))"
