@@ -187,6 +187,8 @@ def main():
     if multi:
         import torch
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")      # (--force-dist without a launcher)
+        os.environ.setdefault("MASTER_PORT", "29517")
         torch.cuda.set_device(local)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))

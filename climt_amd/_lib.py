@@ -80,6 +80,10 @@ def load_library():
     lib.rrtmg_hip_synchronize.argtypes = [_vp]
     lib.rrtmg_hip_set_deferred.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_stream_wait.argtypes = [_vp, _vp]
+    lib.rrtmg_hip_interface_values.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.rrtmg_hip_elementwise.argtypes = [_vp, C.c_int, C.c_long, _vp, _vp, _f64, _f64, _vp]
+    lib.rrtmg_hip_ab_step.argtypes = [_vp, C.c_long, C.c_int, _vp, C.POINTER(_vp), C.POINTER(_f64), _f64, _vp]
+    lib.rrtmg_hip_order_streams.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_zenith_angle.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _vp]
     lib.rrtmg_hip_slab_surface.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(SlabArgs)]
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
@@ -168,6 +172,31 @@ class Context:
     def stream_wait(self, other_stream):
         """`other_stream` (hipStream_t) waits, on the device, for everything enqueued so far on this context's streams."""
         self._ck(self.lib.rrtmg_hip_stream_wait(self.h, _vp(other_stream)))
+
+    # -- glue of the device-resident step (device pointers) ------------------------------------------
+    def interface_values(self, ncol, nlay, mid, surf, pmid, pint, out):
+        self._ck(self.lib.rrtmg_hip_interface_values(self.h, int(ncol), int(nlay), mid, surf, pmid, pint, out))
+
+    def elementwise(self, op, n, a, out, b=None, alpha=1.0, beta=1.0):
+        """op: 'axpby' out = alpha*a (+ beta*b), 'cos' out = cos(a), 'muldiv' out = a*alpha/beta"""
+        self._ck(self.lib.rrtmg_hip_elementwise(self.h, {"axpby": 0, "cos": 1, "muldiv": 2}[op], int(n), a, b, float(alpha), float(beta), out))
+
+    def ab_step(self, n, x, tendencies, weights, dt, out):
+        k = len(tendencies)
+        f = (_vp * k)(*tendencies)
+        w = (_f64 * k)(*weights)
+        self._ck(self.lib.rrtmg_hip_ab_step(self.h, int(n), k, x, f, w, float(dt), out))
+
+    def order_streams(self, direction):
+        self._ck(self.lib.rrtmg_hip_order_streams(self.h, int(direction)))
+
+    def slab_surface_device(self, ncol, ptrs, area_type, tend_ts, depth):
+        """rrtmg_hip_slab_surface on device pointers: `ptrs` maps SLAB_IN names to device addresses."""
+        a = SlabArgs()
+        for k in SLAB_IN:
+            setattr(a, k, int(ptrs[k]))
+        a.area_type, a.tend_ts, a.depth = int(area_type), int(tend_ts), int(depth)
+        self._ck(self.lib.rrtmg_hip_slab_surface(self.h, int(ncol), 1, C.byref(a)))
 
     def zenith_angle(self, lat_deg, lon_deg, julian_centuries, out=None, memspace=0, ncol=None):
         """Zenith angle (radians) of every column; host arrays, or device pointers with memspace=1 (then `ncol`)."""

@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
       if (ctile0 + w < ntile && (d.tile_cld[tile0 + ctile0 + w] != 0) == CLD) mine = true;
     if (!mine) return;
   }
+  if (d.only_item >= 0 && k != d.only_item) return;
   const int slot = T.sched[k], item = T.item[slot];
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
 #ifdef RRTMG_LW_NOLDS
@@ -173,6 +174,8 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.idrv = a->idrv ? 1 : 0;
   d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
+  d.only_item = -1;
+  if (const char *e = getenv("RRTMG_HIP_ONLY_ITEM")) d.only_item = atoi(e);
   d.fluxfac = (2.0 * asin(1.0)) * 2.e4;       // rrtmg_lw_rad.nomcica.f90:420-421
   const bool maxrand = !d.mcica && d.icld >= 2;   // rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544)
   if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");

@@ -80,6 +80,7 @@ struct LwDev {
   double *scratch;
   double *part;        // [item][nk][nlay+1][pcols], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd summed over the item
   int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
+  int only_item;       // diagnostic (env RRTMG_HIP_ONLY_ITEM): >= 0 runs this position of the launch order alone (wrong results; timing)
   int *err;
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
 };

@@ -199,3 +199,93 @@ extern "C" int rrtmg_hip_zenith_angle(rrtmg_ctx *ctx, int ncol, int memspace, co
   RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   return RRTMG_OK;
 }
+
+// ---- glue of the device-resident radiation step --------------------------------------------------------------------------
+// The host-side numpy of the component classes between the kernels -- so that a model loop never leaves HBM:
+//   interface temperatures     get_interface_values            climt/_core/util.py:89-142 (lw/component.py:378-384)
+//   q -> volume mixing ratio   mass_to_volume_mixing_ratio     climt/_core/util.py:47-86  (q * 28.964 / 18.02: two roundings)
+//   cos(zenith)                np.cos(state['zenith_angle'])   sw/component.py:567
+//   tendency sums and the Adams-Bashforth update (sympl AdamsBashforth around the components, tests/test_components.py:123-160)
+namespace rrtmg {
+__global__ void __launch_bounds__(256) interface_values_kernel(int ncol, int nlay, const double *mid, const double *surf, const double *pmid,
+                                                               const double *pint, double *out) {
+  const int col = blockIdx.x * 256 + threadIdx.x, lev = blockIdx.y;
+  if (col >= ncol) return;
+  const long N = ncol;
+  double v;
+  if (lev == 0) v = surf[col];
+  else if (lev == nlay) v = mid[(long)(nlay - 1) * N + col];
+  else {
+    const double lp1 = log(pmid[(long)lev * N + col]), lp0 = log(pmid[(long)(lev - 1) * N + col]);
+    const double weight = (log(pint[(long)lev * N + col]) - lp1) / (lp0 - lp1);
+    const double m1 = mid[(long)lev * N + col], m0 = mid[(long)(lev - 1) * N + col];
+    v = m1 - weight * (m1 - m0);
+  }
+  out[(long)lev * N + col] = v;
+}
+// op 0: out = alpha * a (+ beta * b);  1: out = cos(a);  2: out = a * alpha / beta (the two roundings of util.py:86)
+__global__ void __launch_bounds__(256) elementwise_kernel(int op, long n, const double *a, const double *b, double alpha, double beta, double *out) {
+#pragma clang fp contract(off)   // the host numpy this replaces rounds every product and sum
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  if (op == 0) { const double x = alpha * a[i]; out[i] = b ? x + beta * b[i] : x; }
+  else if (op == 1) out[i] = cos(a[i]);
+  else out[i] = a[i] * alpha / beta;
+}
+// x_out = x + dt * (w0 f0 + w1 f1 + w2 f2 + w3 f3), the sum formed left to right as sympl's stepper does (0 + w0 f0 + ...)
+__global__ void __launch_bounds__(256) ab_step_kernel(long n, int order, const double *x, const double *f0, const double *f1, const double *f2,
+                                                      const double *f3, double w0, double w1, double w2, double w3, double dt, double *out) {
+#pragma clang fp contract(off)
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double incr = 0.0 + w0 * f0[i];
+  if (order > 1) incr = incr + w1 * f1[i];
+  if (order > 2) incr = incr + w2 * f2[i];
+  if (order > 3) incr = incr + w3 * f3[i];
+  out[i] = x[i] + dt * incr;
+}
+}  // namespace rrtmg
+
+extern "C" int rrtmg_hip_interface_values(rrtmg_ctx *ctx, int ncol, int nlay, const double *mid, const double *surf, const double *pmid,
+                                          const double *pint, double *out) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (ncol <= 0 || nlay <= 0 || !mid || !surf || !pmid || !pint || !out) return ctx->fail(RRTMG_ERR_ARG, "interface_values: bad argument");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(interface_values_kernel, dim3((ncol + 255) / 256, nlay + 1), dim3(256), 0, ctx->stream, ncol, nlay, mid, surf, pmid, pint, out);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTMG_OK;
+}
+extern "C" int rrtmg_hip_elementwise(rrtmg_ctx *ctx, int op, long n, const double *a, const double *b, double alpha, double beta, double *out) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (n <= 0 || op < 0 || op > 2 || !a || !out) return ctx->fail(RRTMG_ERR_ARG, "elementwise: bad argument");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(elementwise_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, op, n, a, b, alpha, beta, out);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTMG_OK;
+}
+extern "C" int rrtmg_hip_ab_step(rrtmg_ctx *ctx, long n, int order, const double *x, const double *const *f, const double *w, double dt, double *out) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (n <= 0 || order < 1 || order > 4 || !x || !f || !w || !out) return ctx->fail(RRTMG_ERR_ARG, "ab_step: bad argument");
+  for (int k = 0; k < order; ++k)
+    if (!f[k]) return ctx->fail(RRTMG_ERR_ARG, "ab_step: tendency %d is NULL", k);
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipLaunchKernelGGL(ab_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, order, x, f[0], order > 1 ? f[1] : nullptr,
+                     order > 2 ? f[2] : nullptr, order > 3 ? f[3] : nullptr, w[0], order > 1 ? w[1] : 0.0, order > 2 ? w[2] : 0.0, order > 3 ? w[3] : 0.0, dt, out);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTMG_OK;
+}
+// direction 0: the longwave stream waits for everything enqueued so far on the main stream (inputs prepared there);
+// direction 1: the main stream waits for the longwave stream (its outputs are consumed there).  Host does not block.
+extern "C" int rrtmg_hip_order_streams(rrtmg_ctx *ctx, int direction) {
+  if (!ctx || !ctx->stream || !ctx->stream_lw) return RRTMG_ERR_ARG;
+  hipStream_t from = direction == 0 ? ctx->stream : ctx->stream_lw, to = direction == 0 ? ctx->stream_lw : ctx->stream;
+  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->sync_ev[direction ? 1 : 0], from));
+  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(to, ctx->sync_ev[direction ? 1 : 0], 0));
+  return RRTMG_OK;
+}

@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
 #endif
   const int k = q / ngrp;
+  if (d.only_item >= 0 && k != d.only_item) return;
   const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
 #if RRTMG_SW_KLDS
   constexpr bool kLdsK = true;
@@ -180,6 +181,7 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
       if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
     if (!mine) return;
   }
+  if (d.only_item >= 0 && k != d.only_item) return;
   const int id = T.sched[1][k], item = T.item[1][id], slot = item_iw0(item) >> 1;
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 2];
   sw_stage_slice(T, item, sh_k, 64 * kSwCldWgWaves);
@@ -296,6 +298,8 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (d.iaer != 0 && d.iaer != 6 && d.iaer != 10) d.iaer = 0;
   d.inflag = a->inflgsw; d.iceflag = a->iceflgsw; d.liqflag = a->liqflgsw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
+  d.only_item = -1;
+  if (const char *e = getenv("RRTMG_HIP_ONLY_ITEM")) d.only_item = atoi(e);
   std::string err;
   std::vector<double> svar_col;
   {

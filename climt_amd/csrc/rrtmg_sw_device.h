@@ -98,6 +98,7 @@ struct SwDev {
   double *scratch;     // [tile][item: first g-point * ...][lay][field][G][64]
   double *part;        // [slot][4][nlay+1][pcols]  weighted (fu, fd, cu, cd) of the columns col0 .. col0+pcols-1
   int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
+  int only_item;       // diagnostic (env RRTMG_HIP_ONLY_ITEM): >= 0 runs this position of the launch order alone (wrong results; timing)
   int *err;
   // outputs
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;

@@ -37,6 +37,14 @@ class Instellation(DiagnosticComponent):
         super(Instellation, self).__init__(**kwargs)
         self._ctx = context if context is not None else make_context(device)
 
+    def __call__(self, state, *args, **kwargs):
+        """A host state goes through sympl's machinery to array_call; a climt_amd.DeviceState (state resident in HBM) takes
+        the device path: same quantities, DeviceQuantity handles instead of arrays (climt_amd/device_state.py)."""
+        from .device_state import DeviceState, instellation_device_call
+        if isinstance(state, DeviceState):
+            return instellation_device_call(self, state)
+        return super(Instellation, self).__call__(state, *args, **kwargs)
+
     def array_call(self, state):
         lat, lon = state["latitude"], state["longitude"]
         lat_flat = np.ascontiguousarray(np.reshape(lat, (-1,)), dtype=np.float64)

@@ -117,6 +117,14 @@ class RRTMGLongwave(TendencyComponent):
         self.change_in_clear_sky_upward_flux_with_surface_temperature = None
         super(RRTMGLongwave, self).__init__(**kwargs)
 
+    def __call__(self, state, *args, **kwargs):
+        """A host state goes through sympl's machinery to array_call; a climt_amd.DeviceState (state resident in HBM) takes
+        the device path: same quantities, DeviceQuantity handles instead of arrays (climt_amd/device_state.py)."""
+        from ..device_state import DeviceState, longwave_device_call
+        if isinstance(state, DeviceState):
+            return longwave_device_call(self, state)
+        return super(RRTMGLongwave, self).__call__(state, *args, **kwargs)
+
     @ensure_contiguous_state
     def array_call(self, state):
         """Longwave heating tendency and up/down fluxes (all-sky and clear-sky)."""

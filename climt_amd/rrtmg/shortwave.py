@@ -123,6 +123,14 @@ class RRTMGShortwave(TendencyComponent):
         self._ctx.sw_init(self._Cpd)
         super(RRTMGShortwave, self).__init__(**kwargs)
 
+    def __call__(self, state, *args, **kwargs):
+        """A host state goes through sympl's machinery to array_call; a climt_amd.DeviceState (state resident in HBM) takes
+        the device path: same quantities, DeviceQuantity handles instead of arrays (climt_amd/device_state.py)."""
+        from ..device_state import DeviceState, shortwave_device_call
+        if isinstance(state, DeviceState):
+            return shortwave_device_call(self, state)
+        return super(RRTMGShortwave, self).__call__(state, *args, **kwargs)
+
     @ensure_contiguous_state
     def array_call(self, state):
         """Shortwave heating tendency and up/down fluxes (all-sky and clear-sky)."""

@@ -54,6 +54,14 @@ class SlabSurface(TendencyComponent):
         super(SlabSurface, self).__init__(**kwargs)
         self._ctx = context if context is not None else make_context(device)
 
+    def __call__(self, state, *args, **kwargs):
+        """A host state goes through sympl's machinery to array_call; a climt_amd.DeviceState (state resident in HBM) takes
+        the device path: same quantities, DeviceQuantity handles instead of arrays (climt_amd/device_state.py)."""
+        from .device_state import DeviceState, slab_device_call
+        if isinstance(state, DeviceState):
+            return slab_device_call(self, state)
+        return super(SlabSurface, self).__call__(state, *args, **kwargs)
+
     def array_call(self, state):
         area_type_raw = state["area_type"]
         area_type_str = np.asarray(area_type_raw).astype(str)

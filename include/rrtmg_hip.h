@@ -133,6 +133,19 @@ typedef struct rrtmg_slab_args {
 } rrtmg_slab_args;
 int rrtmg_hip_slab_surface(rrtmg_ctx *ctx, int ncol, int memspace, const rrtmg_slab_args *args);
 
+/* ---- glue of a device-resident radiation step (device pointers only; enqueued on the context's main stream) ----------
+ * The numpy that climt's component classes run on the host between the kernels, so that a model loop can stay in HBM. */
+/* interface values of a mid-level quantity by log-pressure interpolation, [nlay+1][ncol]: climt/_core/util.py:89-142 */
+int rrtmg_hip_interface_values(rrtmg_ctx *ctx, int ncol, int nlay, const double *mid, const double *surf, const double *pmid,
+                               const double *pint, double *out);
+/* op 0: out = alpha*a (+ beta*b if b != NULL); op 1: out = cos(a) (sw/component.py:567); op 2: out = a*alpha/beta
+ * (mass_to_volume_mixing_ratio, util.py:86, with its two roundings) */
+int rrtmg_hip_elementwise(rrtmg_ctx *ctx, int op, long n, const double *a, const double *b, double alpha, double beta, double *out);
+/* Adams-Bashforth update out = x + dt * sum_k w[k] f[k], k < order <= 4 (f, w: host arrays of device pointers / weights) */
+int rrtmg_hip_ab_step(rrtmg_ctx *ctx, long n, int order, const double *x, const double *const *f, const double *w, double dt, double *out);
+/* deferred mode: 0 = the longwave stream waits for the main stream's work so far, 1 = the main stream waits for the longwave's */
+int rrtmg_hip_order_streams(rrtmg_ctx *ctx, int direction);
+
 /* ---- shortwave ------------------------------------------------------------------------ */
 typedef struct rrtmg_sw_args {
   int32_t ncol, nlay;

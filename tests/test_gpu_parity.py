@@ -4,6 +4,7 @@ Bars (north_star): fluxes <= 0.01 W m^-2, heating rates <= 0.001 K day^-1 agains
 device path actually agrees to ~1e-9, which is what is asserted."""
 import ctypes as C
 import os
+import re
 
 import numpy as np
 import pytest
@@ -652,8 +653,10 @@ def _shard_size_checks(gpu_ctx, ncol, nlay, sample, seed):
     pick = {k: (np.ascontiguousarray(np.take(v, idx, axis=COLUMN_AXIS[k])) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
     esw, elw, kind = live_oracle(pick, True, chunk=128)
     print("oracle:", kind, "sample", len(idx))
-    _check({k: v[:, idx] for k, v in sw.items()}, esw)
-    _check({k: v[:, idx] for k, v in lw.items()}, elw)
+    # (thousands of columns: some hit reftra's ill-conditioned spot k*mu0 ~ 1, see test_randomised_shapes...; 1e-7 W m-2
+    #  is still five orders of magnitude inside the 0.01 W m-2 bar)
+    _check({k: v[:, idx] for k, v in sw.items()}, esw, tight=1.0e-7)
+    _check({k: v[:, idx] for k, v in lw.items()}, elw, tight=1.0e-7)
     # (2) idempotence, bit for bit
     sw2 = gpu_ctx.sw_fluxes(c, mcica=True)
     assert all(np.array_equal(sw[k], sw2[k]) for k in sw)
@@ -684,3 +687,76 @@ def test_config5_shard_size_129600x100(gpu_ctx):
     """BASELINE configs[4]: 1440x720x100 over 8 GPUs = 129 600 columns x 100 levels per GPU (2025 tiles: four solve
     chunks of 512 tiles, the last one ragged)."""
     _shard_size_checks(gpu_ctx, 129600, 100, 4096, 42)
+
+
+# ---- the radiation step with the state resident in HBM (SURVEY.md 8(f)3) ------------------------------------------------
+def _radiation_loop(device_resident, steps=4, mcica=True):
+    """Instellation -> RRTMGShortwave + RRTMGLongwave -> Adams-Bashforth -> SlabSurface, as examples/gmd_aquaplanet.py:61-104
+    arranges them (radiation behind UpdateFrequencyWrapper), on the host state or on a DeviceState."""
+    import datetime as dtm
+    import climt_amd
+    np.random.seed(3)
+    kw = dict(mcica=True, random_number_generator="kissvec", cloud_overlap_method="maximum_random") if mcica else {}
+    sun = climt_amd.Instellation()
+    sw = climt_amd.UpdateFrequencyWrapper(climt_amd.RRTMGShortwave(**kw), dtm.timedelta(minutes=20))
+    lw = climt_amd.UpdateFrequencyWrapper(climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **kw), dtm.timedelta(minutes=20))
+    slab = climt_amd.SlabSurface()
+    state = climt_amd.get_default_state([sun, sw, lw, slab], grid_state=climt_amd.get_grid(nx=24, ny=12, nz=32))
+    p = state["air_pressure"].values
+    state["air_temperature"].values[:] = np.maximum(200.0, 290.0 * (p / 1.0e5) ** 0.19)
+    state["specific_humidity"].values[:] = 0.012 * (p / 1.0e5) ** 3
+    cld = (p > 4.0e4) & (p < 8.0e4)
+    state["cloud_area_fraction_in_atmosphere_layer"].values[:] = np.where(cld, 0.4, 0.0) if mcica else 0.0
+    state["mass_content_of_cloud_liquid_water_in_atmosphere_layer"].values[:] = np.where(cld, 0.03, 0.0)
+    state["surface_longwave_emissivity"].values[:] = 0.97
+    dt = dtm.timedelta(minutes=10)
+    if device_resident:
+        st = climt_amd.DeviceState.from_host(state, [sun, sw, lw, slab])
+        stepper = climt_amd.DeviceAdamsBashforth(sw, lw, slab)
+    else:
+        st, stepper = state, climt_amd.AdamsBashforth(sw, lw, slab)
+    for _ in range(steps):
+        st.update(sun(st))
+        diag, st = stepper(st, dt)          # as examples/gmd_aquaplanet.py:94-96: the new state, then the diagnostics into it
+        st.update(diag)
+        st["time"] = st["time"] + dt
+    names = ("air_temperature", "surface_temperature", "zenith_angle", "upwelling_longwave_flux_in_air", "downwelling_shortwave_flux_in_air",
+             "air_temperature_tendency_from_shortwave", "air_temperature_tendency_from_longwave_assuming_clear_sky", "depth_of_slab_surface")
+    if device_resident:
+        assert all(isinstance(st[n], climt_amd.DeviceQuantity) for n in names)
+        return {n: st.download(n) for n in names}
+    return {n: st[n] for n in names}
+
+
+@pytest.mark.parametrize("mcica", [False, True])
+def test_device_resident_radiation_step_equals_the_host_path(mcica):
+    """The same component instances on a DeviceState (state uploaded once; interface temperatures, vmr, cos(zenith), tendency
+    sums and the Adams-Bashforth update as kernels; SW || LW on two streams; the slab reading the surface rows in place) against
+    the host path that round-trips numpy through every component: 4 steps of 10 min with radiation refreshed every 20 min."""
+    host = _radiation_loop(False, mcica=mcica)
+    dev = _radiation_loop(True, mcica=mcica)
+    for n, h in host.items():
+        d = dev[n]
+        g = np.transpose(d.values, [d.dims.index(x) for x in h.dims])
+        scale = max(1.0, float(np.abs(h.values).max()))
+        assert g.shape == h.values.shape and maxdiff(g, h.values) <= 1.0e-9 * scale, (n, maxdiff(g, h.values))
+    assert float(np.abs(host["air_temperature_tendency_from_shortwave"].values).max()) > 0.1      # daylight columns exist
+    assert float(np.abs(host["surface_temperature"].values - 300.0).max()) > 0.0                    # the slab moved
+
+
+def test_radiation_column_example_runs_in_both_modes():
+    """examples/radiation_column.py (the radiation part of examples/gmd_aquaplanet.py on this package alone), host state and
+    --device-resident, print the same diagnostics."""
+    import subprocess
+    import sys
+    outs = []
+    for extra in ([], ["--device-resident"]):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "examples", "radiation_column.py"), "--nx", "16", "--ny", "8", "--nz", "24", "--hours", "2"] + extra,
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, RRTMG_HIP_ALLOW_SYNTHETIC_LW="1"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows = [l for l in p.stdout.splitlines() if "OLR" in l]
+        assert len(rows) >= 2
+        outs.append(rows)
+    for a, b in zip(*outs):
+        va, vb = [float(x) for x in re.findall(r"-?\d+\.\d+", a)], [float(x) for x in re.findall(r"-?\d+\.\d+", b)]
+        np.testing.assert_allclose(va, vb, rtol=0, atol=2e-3)      # printed to 2-3 decimals
