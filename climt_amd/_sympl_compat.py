@@ -128,7 +128,7 @@ except ImportError:
                 da = state[name]
                 values, dims = np.asarray(da.values), tuple(da.dims)
                 if values.dtype.kind in "fiub":     # numeric; string quantities (area_type) pass through
-                    values = convert_units(values.astype(np.float64), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
+                    values = convert_units(values.astype(np.float64, copy=False), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
                 want = list(prop["dims"])
                 named = [d for d in want if d != "*"]
                 for d in named:

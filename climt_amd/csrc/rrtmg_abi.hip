@@ -45,6 +45,43 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   return RRTMG_OK;
 }
 
+int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host) {
+  size_t total = 0;
+  for (int i = 0; i < count; ++i) total += o[i].n * sizeof(double);
+  if (total > ctx->pinned_cap) {
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    ctx->pinned = nullptr; ctx->pinned_cap = 0;
+    RRTMG_HIP_CHECK(ctx, hipHostMalloc(&ctx->pinned, total, hipHostMallocDefault));
+    ctx->pinned_cap = total;
+  }
+  char *p = (char *)ctx->pinned;
+  if (herr_dev) RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(herr_host, herr_dev, sizeof(int), hipMemcpyDeviceToHost, s));
+  size_t off = 0;
+  for (int i = 0; i < count; ++i) {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(p + off, o[i].dev, o[i].n * sizeof(double), hipMemcpyDeviceToHost, s));
+    off += o[i].n * sizeof(double);
+  }
+  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  // pinned staging -> the caller's arrays, in slices on a few host threads (first touch of fresh pages dominates)
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+  if (total < (size_t)4 << 20) nt = 1;
+  std::vector<std::thread> th;
+  auto work = [&](unsigned t) {
+    size_t off2 = 0;
+    for (int i = 0; i < count; ++i) {
+      const size_t bytes = o[i].n * sizeof(double), per = (bytes / nt + 4095) & ~(size_t)4095;
+      const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
+      if (lo < bytes) memcpy((char *)o[i].host + lo, p + off2 + lo, hi - lo);
+      off2 += bytes;
+    }
+  };
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  return RRTMG_OK;
+}
+
 std::string default_blob_path(const char *which) {
   if (const char *env = getenv(strcmp(which, "sw") == 0 ? "RRTMG_HIP_SW_DATA" : "RRTMG_HIP_LW_DATA")) return env;
   Dl_info info;
@@ -88,6 +125,7 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
   if (ctx->sw_tab_dev) (void)hipFree(ctx->sw_tab_dev);
   if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
   if (ctx->err_dev) (void)hipFree(ctx->err_dev);
+  if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int w = 0; w < 4; ++w)
     for (int k = 0; k < 2; ++k)
       if (ctx->ev[w][k]) (void)hipEventDestroy(ctx->ev[w][k]);

@@ -4,8 +4,10 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrtmg_hip.h"
@@ -48,6 +50,9 @@ struct rrtmg_ctx {
   void *sw_desc = nullptr, *lw_desc = nullptr;   // SwTab / LwTab (host copies, owned)
   // grow-only device work buffers, by name
   std::map<std::string, rrtmg::DevBuf> bufs;
+  // grow-only PINNED host staging for the outputs of host-pointer calls (see copy_out)
+  void *pinned = nullptr;
+  size_t pinned_cap = 0;
   int *err_dev = nullptr;
   // HIP events around the solve launches of the last column chunk: [0] sw clear-sky kernel, [1] lw clear-sky variant,
   // [2] sw cloudy kernel, [3] lw cloudy variant; [start|stop]
@@ -82,6 +87,17 @@ struct rrtmg_ctx {
     return b.p;
   }
 };
+
+namespace rrtmg {
+// Outputs of a host-pointer (memspace = 0) call.  The caller's arrays are normally FRESH allocations (climt hands every call
+// new zero-filled numpy arrays, lw/component.py:386-399): a device-to-host copy straight into never-touched pageable memory
+// runs at < 1 GB/s (the runtime pins it page by page; measured 27 ms for 24 MB), while a copy into pinned staging runs at
+// 56 GB/s and a few host threads first-touch and fill the caller's pages at > 10 GB/s (tools/micro/host_path_timing.py).
+// interface values of a mid-level quantity (climt/_core/util.py:89-142) on stream s, device pointers
+void launch_interface_values(hipStream_t s, int ncol, int nlay, const double *mid, const double *surf, const double *pmid, const double *pint, double *out);
+struct OutCopy { double *host; const double *dev; size_t n; };
+int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host);
+}  // namespace rrtmg
 
 #define RRTMG_HIP_CHECK(ctx, call)                                                                     \
   do {                                                                                                 \

@@ -193,7 +193,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     return dp;
   };
   d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
-  d.tlev = in(a->tlev, nl1, "tlev", true); d.tsfc = in(a->tsfc, N, "tsfc", true);
+  d.tlev = in(a->tlev, nl1, "tlev", false); d.tsfc = in(a->tsfc, N, "tsfc", true);
   d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
   d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
   d.cfc11 = in(a->cfc11vmr, nl, "cfc11", false); d.cfc12 = in(a->cfc12vmr, nl, "cfc12", false);
@@ -249,6 +249,14 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   }   // deferred: the flag accumulates (atomicMax) until rrtmg_hip_synchronize collects and clears it
 
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
+  if (!d.tlev) {
+    // no interface temperatures given: log-pressure interpolation of the layer temperatures on the device, as climt's
+    // host does before the call when calculate_interface_temperature is set (lw/component.py:378-384, util.py:89-142)
+    double *tl = wd("tlev", nl1);
+    if (!ok) return ctx->status;
+    launch_interface_values(s, N, L, d.tlay, d.tsfc, d.play, d.plev, tl);
+    d.tlev = tl;
+  }
   hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
   hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
   if (clouds) {
@@ -301,20 +309,15 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
 
   if (ctx->deferred && a->memspace == 1) { ctx->pending[1] = true; ctx->status = 0; return RRTMG_OK; }
   int herr = 0;
-  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
   if (a->memspace == 0) {
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->uflx, d.uflx, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->dflx, d.dflx, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->uflxc, d.uflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->dflxc, d.dflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->hr, d.hr, nl * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->hrc, d.hrc, nl * 8, hipMemcpyDeviceToHost, s));
-    if (d.idrv) {
-      RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->duflx_dt, d.duflx_dt, nl1 * 8, hipMemcpyDeviceToHost, s));
-      RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->duflxc_dt, d.duflxc_dt, nl1 * 8, hipMemcpyDeviceToHost, s));
-    }
+    const OutCopy oc[8] = {{a->uflx, d.uflx, nl1}, {a->dflx, d.dflx, nl1}, {a->uflxc, d.uflxc, nl1}, {a->dflxc, d.dflxc, nl1},
+                           {a->hr, d.hr, nl}, {a->hrc, d.hrc, nl}, {a->duflx_dt, d.duflx_dt, nl1}, {a->duflxc_dt, d.duflxc_dt, nl1}};
+    rc = copy_out(ctx, s, oc, d.idrv ? 8 : 6, d.err, &herr);
+    if (rc) return rc;
+  } else {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   }
-  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   if (herr) return ctx->fail(herr, "longwave: %s", status_message(herr));
   ctx->status = 0;
   return RRTMG_OK;

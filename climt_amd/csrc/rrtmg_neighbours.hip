@@ -244,6 +244,9 @@ __global__ void __launch_bounds__(256) ab_step_kernel(long n, int order, const d
   if (order > 3) incr = incr + w3 * f3[i];
   out[i] = x[i] + dt * incr;
 }
+void launch_interface_values(hipStream_t s, int ncol, int nlay, const double *mid, const double *surf, const double *pmid, const double *pint, double *out) {
+  hipLaunchKernelGGL(interface_values_kernel, dim3((ncol + 255) / 256, nlay + 1), dim3(256), 0, s, ncol, nlay, mid, surf, pmid, pint, out);
+}
 }  // namespace rrtmg
 
 extern "C" int rrtmg_hip_interface_values(rrtmg_ctx *ctx, int ncol, int nlay, const double *mid, const double *surf, const double *pmid,

@@ -333,10 +333,13 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds) {
     d.cldfr = in(a->cldfr, nl, "cldfr", true);
     const bool optics = (d.inflag == 0);
-    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics);
-    d.ssacld = in(a->ssacld, nl * kSwNBand, "ssacld", optics);
-    d.asmcld = in(a->asmcld, nl * kSwNBand, "asmcld", optics);
-    d.fsfcld = in(a->fsfcld, nl * kSwNBand, "fsfcld", optics);
+    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
+    // single-scattering albedo / asymmetry / forward fraction are read only where the optics are given directly -- under
+    // inflag 2 they would multiply an optical depth below cldmin = 1e-20 at most -- so host copies are not uploaded then
+    const bool up = optics || a->memspace == 1;
+    d.ssacld = up ? in(a->ssacld, nl * kSwNBand, "ssacld", optics) : nullptr;
+    d.asmcld = up ? in(a->asmcld, nl * kSwNBand, "asmcld", optics) : nullptr;
+    d.fsfcld = up ? in(a->fsfcld, nl * kSwNBand, "fsfcld", optics) : nullptr;
     d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag == 2); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag == 2);
     d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
   }
@@ -445,16 +448,15 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   // ---- status + outputs -------------------------------------------------------------------
   if (ctx->deferred && a->memspace == 1) { ctx->pending[0] = true; ctx->status = 0; return RRTMG_OK; }
   int herr = 0;
-  RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
   if (a->memspace == 0) {
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swuflx, d.swuflx, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swdflx, d.swdflx, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swuflxc, d.swuflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swdflxc, d.swdflxc, nl1 * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swhr, d.swhr, nl * 8, hipMemcpyDeviceToHost, s));
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(a->swhrc, d.swhrc, nl * 8, hipMemcpyDeviceToHost, s));
+    const OutCopy oc[6] = {{a->swuflx, d.swuflx, nl1}, {a->swdflx, d.swdflx, nl1}, {a->swuflxc, d.swuflxc, nl1}, {a->swdflxc, d.swdflxc, nl1},
+                           {a->swhr, d.swhr, nl}, {a->swhrc, d.swhrc, nl}};
+    rc = copy_out(ctx, s, oc, 6, d.err, &herr);
+    if (rc) return rc;
+  } else {
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, d.err, sizeof(int), hipMemcpyDeviceToHost, s));
+    RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   }
-  RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   if (herr) return ctx->fail(herr, "shortwave: %s", status_message(herr));
   ctx->status = 0;
   return RRTMG_OK;

@@ -136,8 +136,8 @@ class RRTMGShortwave(TendencyComponent):
         """Shortwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
         Q = mass_to_volume_mixing_ratio(state["specific_humidity"], 18.02)
         assert state["air_pressure"].shape[0] + 1 == state["air_pressure_on_interface_levels"].shape[0]
-        Tint = get_interface_values(state["air_temperature"], state["surface_temperature"], state["air_pressure"],
-                                    state["air_pressure_on_interface_levels"])
+        # (the reference also interpolates interface temperatures here, sw/component.py:492-496; RRTMG_SW never reads them)
+        Tint = None
         diagnostics = initialize_numpy_arrays_with_properties(self.diagnostic_properties, state, self.input_properties)
         tendencies = initialize_numpy_arrays_with_properties(self.tendency_properties, state, self.input_properties)
         day_of_year = 0 if self._ignore_day_of_year else state["time"].timetuple().tm_yday

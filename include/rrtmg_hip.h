@@ -197,7 +197,8 @@ typedef struct rrtmg_lw_args {
   int32_t irng, permuteseed;
   int32_t shard_col0, shard_ncol;                    /* see rrtmg_sw_args */
   int32_t reserved0;
-  const double *play, *plev, *tlay, *tlev, *tsfc;
+  const double *play, *plev, *tlay, *tlev, *tsfc;      /* tlev NULL: interpolated on the device from tlay, tsfc, play, plev as
+                                                         * climt's get_interface_values does (util.py:89-142) */
   const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;
   const double *cfc11vmr, *cfc12vmr, *cfc22vmr, *ccl4vmr;
   const double *emis;                                /* [16][ncol] */

@@ -58,6 +58,21 @@ extern "C" int emu_lw_fluxes(const rrtmg_lw_args *a, const char *blob_path, doub
   d.play = a->play; d.plev = a->plev; d.tlay = a->tlay; d.tlev = a->tlev; d.tsfc = a->tsfc; d.h2o = a->h2ovmr; d.o3 = a->o3vmr;
   d.co2 = a->co2vmr; d.ch4 = a->ch4vmr; d.n2o = a->n2ovmr; d.o2 = a->o2vmr; d.cfc11 = a->cfc11vmr; d.cfc12 = a->cfc12vmr;
   d.cfc22 = a->cfc22vmr; d.ccl4 = a->ccl4vmr; d.emis = a->emis; d.tauaer = a->tauaer;
+  std::vector<double> tlev_host;
+  if (!d.tlev) {   // interface temperatures not given: the interpolation the library does on the device (util.py:89-142)
+    tlev_host.resize(nl1);
+    for (int c = 0; c < N; ++c) {
+      tlev_host[c] = d.tsfc[c];
+      tlev_host[(size_t)L * N + c] = d.tlay[(size_t)(L - 1) * N + c];
+      for (int lev = 1; lev < L; ++lev) {
+        const double lp1 = log(d.play[(size_t)lev * N + c]), lp0 = log(d.play[(size_t)(lev - 1) * N + c]);
+        const double w = (log(d.plev[(size_t)lev * N + c]) - lp1) / (lp0 - lp1);
+        const double m1 = d.tlay[(size_t)lev * N + c], m0 = d.tlay[(size_t)(lev - 1) * N + c];
+        tlev_host[(size_t)lev * N + c] = m1 - w * (m1 - m0);
+      }
+    }
+    d.tlev = tlev_host.data();
+  }
   const bool clouds = d.icld >= 1;
   if (clouds) { d.cldfr = a->cldfr; d.taucld = a->taucld; d.cicewp = a->cicewp; d.cliqwp = a->cliqwp; d.reice = a->reice; d.reliq = a->reliq; }
   std::vector<std::vector<double>> keep;
