@@ -1,16 +1,17 @@
 // rrtmg_sw_device.h -- RRTMG shortwave hot path as per-thread device functions (gfx950).
 //
-// Decomposition (MI355X-first, not the reference's per-column serial loops):
-//   sw_prep_column   one thread per column : inatm_sw + setcoef_sw + laysolfr bookkeeping
-//   sw_cloud_layer   one thread per (column, layer) : cldprop_sw / cldprmc_sw band optics
-//   sw_kiss_column   one thread per column : kissvec sub-column cloud mask (bit-packed)
-//   sw_solve_thread  one thread per (column, g-point); a wavefront = 64 columns x ONE g-point, so
-//                    band/g-point control flow is wave-uniform, every per-column input is a
-//                    coalesced 512-B row of the [layer][column] arrays, and k-table gathers of a
-//                    wave fall in one contiguous [g][index] slice.  Two sweeps over the layers:
-//                    up (taumol + delta scaling + reftra + upward adding recurrence, level state
-//                    spilled to a [layer][field][lane] scratch slab) and down (downward adding
-//                    recurrence + flux assembly).
+// Decomposition (MI355X-first, not the reference's per-column serial loops); kernels in rrtmg_sw.hip:
+//   sw_prep_layer    one thread per (column, layer): inatm_sw + setcoef_sw -> one row set of the prep slab
+//   sw_prep_column   one thread per (column, band): laytrop, cloud flags, the layer each band takes its solar source from
+//   sw_cloud_layer   one thread per (column, layer): cldprop_sw / cldprmc_sw band optics (delta-scaled)
+//   kiss_mask_jump   one thread per (column, sub-column): kissvec sub-column cloud mask, bit-packed, by jump-ahead
+//   sw_solve_thread  one thread per (column, work item); a work item = 4 or 2 consecutive g-points of ONE band carried
+//                    through both sweeps by the thread, a wavefront = 64 columns x one item: band control flow is
+//                    wave-uniform, every per-column input is a coalesced 512-B row, the item's k-distribution slice
+//                    [row][G] sits in LDS.  Sweep 1 (bottom-up): taumol + delta scaling + reftra + upward adding
+//                    recurrence, (rup, rupd) spilled to a [layer][field][lane][G] scratch slab; sweep 2 (top-down):
+//                    the layer optics again (recomputed, not stored), downward recurrence and the fluxes at every
+//                    interface, summed over the item's g-points into part[slot][k][level][column].
 //   sw_flux_level / sw_heat_layer  spectral integration in g-point order; heating rates.
 //
 // Reference followed (climt/_lib/rrtmg_sw/): rrtmg_sw_rad.nomcica.f90:587-816 (driver),

@@ -136,6 +136,29 @@ class EmuContext:
 REF_CASES = ("clear_L60", "clear_L30", "overcast_L60", "mcica_kiss_random", "mcica_kiss_maxrand", "mcica_mt_max")
 
 
+def input_hash(c):
+    """sha256 over every input array (name, shape, bytes) and scalar of a boundary-level input dict."""
+    import hashlib
+    h = hashlib.sha256()
+    for k in sorted(c):
+        v = c[k]
+        if isinstance(v, np.ndarray):
+            a = np.ascontiguousarray(v, dtype=np.float64)
+            h.update(("%s%s" % (k, a.shape)).encode()); h.update(a.tobytes())
+        else:
+            h.update(("%s=%r" % (k, float(v))).encode())
+    return h.hexdigest()
+
+
+def _check_pinned_inputs(name, c):
+    """The older fixtures store generator arguments, not inputs: tests/golden/input_hashes.json pins what the generator
+    (climt_amd.synthetic) must reproduce, so that a change there cannot silently redefine golden inputs."""
+    import json
+    want = json.load(open(os.path.join(GOLDEN, "input_hashes.json")))[name]
+    got = input_hash(c)
+    assert got == want, "inputs of fixture %s changed (climt_amd.synthetic no longer reproduces them): %s != %s" % (name, got, want)
+
+
 def load_ref_case(name):
     """-> (inputs dict at the C-ABI boundary, mcica flag, expected {'sw': {...}, 'lw': {...}})."""
     from climt_amd.synthetic import make_columns, overcast
@@ -148,6 +171,7 @@ def load_ref_case(name):
         c = overcast(c)
     mcica = bool(flags.pop("_mcica"))
     c.update(flags)
+    _check_pinned_inputs("ref_" + name, c)
     exp = {"sw": {k[3:]: z[k] for k in z.files if k.startswith("sw/")}, "lw": {k[3:]: z[k] for k in z.files if k.startswith("lw/")}}
     return c, mcica, exp
 
@@ -182,6 +206,7 @@ def load_lwmr_case(name):
     c = make_columns(40, 60, cloudy=True, seed=int(z["flag/seed"]))
     c["cldfr"] = np.ascontiguousarray(z["in/cldfr"])
     c.update(icld=int(z["flag/icld"]), iaer=0, inflg=2, iceflg=1, liqflg=1, idrv=int(z["flag/idrv"]))
+    _check_pinned_inputs("ref_lwmr_" + name, c)
     return c, {k[3:]: z[k] for k in z.files if k.startswith("lw/")}
 
 

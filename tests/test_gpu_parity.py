@@ -524,7 +524,8 @@ def test_plain_c_host_gets_the_same_numbers_as_the_python_host(gpu_ctx, tmp_path
 @pytest.mark.parametrize("seed", range(12))
 def test_randomised_shapes_and_flags_against_emulation(gpu_ctx, seed):
     """Seeded random draws of (columns, layers, McICA on/off, overlap mode, dF/dT, clear column blocks that cut across the
-    64-column tiles and the 4 / 12 / 16-tile workgroups) -- device against the host emulation of the same functions."""
+    64-column tiles and the 4 / 12 / 16-tile workgroups) -- the device against the REFERENCE FORTRAN run here when its library
+    travelled (oracle/_ref), and against the host emulation of the same device functions (incl. the dF/dT outputs)."""
     from helpers import EmuContext
     from climt_amd.synthetic import make_columns, overcast
     rng = np.random.default_rng(4200 + seed)
@@ -547,9 +548,18 @@ def test_randomised_shapes_and_flags_against_emulation(gpu_ctx, seed):
     # ill-conditioned -- a g-point/layer with k*mu0 ~ 1, where its denominators (1 - (k mu0)^2)(..) pass through zero
     # (rrtmg_sw_reftra.f90:250-300; the reference guards only the exact zero).  Seed 3 has such a spot: 9e-8 W m-2 with
     # the device's one-reciprocal form, 1.3e-7 with the reference's own operation order on the device.  Hence 1e-6.
-    _check(gpu_ctx.sw_fluxes(c, mcica=mcica), emu.sw_fluxes(c, mcica=mcica), tight=1.0e-6)
+    gsw = gpu_ctx.sw_fluxes(c, mcica=mcica)
+    _check(gsw, emu.sw_fluxes(c, mcica=mcica), tight=1.0e-6)
     got, exp = gpu_ctx.lw_fluxes(c, mcica=mcica), emu.lw_fluxes(c, mcica=mcica)
     _check(got, {k: v for k, v in exp.items() if k in got}, tight=5.0e-8)
+    from oracle import ref_driver
+    if ref_driver.available("sw") and ref_driver.available("lw"):
+        from helpers import live_oracle
+        c.pop("lat", None)
+        rsw, rlw, kind = live_oracle(c, mcica, chunk=256, procs=8)
+        assert kind == "reference"
+        _check(gsw, rsw, tight=1.0e-6)
+        _check({k: got[k] for k in rlw}, rlw, tight=5.0e-8)
 
 
 # ---- option coverage on the device ---------------------------------------------------------------------------------

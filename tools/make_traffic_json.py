@@ -1,34 +1,51 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json from the PMC passes of tools/collect_profiles.sh (profiles/<round>_pmc_{clear,cloudy}_{FETCH,WRITE}_SIZE.txt):
-HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB -- FETCH_SIZE doubled per the gfx950 correction of
-MI355X_MICROARCH.md (HBM section).  Key: "<kernel>|<columns>|<levels>|<clear|cloudy>" (what bench.py looks up).
-usage: tools/make_traffic_json.py [round=r01] [columns=8192] [levels=60]"""
+"""profiles/hbm_traffic.json and profiles/fp64_flops.json from the PMC passes of tools/gpu_session.sh
+(profiles/<round>_pmc_{clear,cloudy}_{FETCH,WRITE}_SIZE[_131072].txt, profiles/<round>_pmc_{clear,cloudy}_sq.txt).
+
+  traffic  = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- FETCH_SIZE doubled per the gfx950 correction of
+             MI355X_MICROARCH.md (HBM section: 128-B requests tallied at 64 B); memory-side requests of the L2s, i.e. HBM plus
+             Infinity-Cache hits.  The 131072-column passes (4 solve chunks of 32768 columns per call, prep slab 0.9-1.6 GB,
+             scratch 9-14 GB per chunk: far beyond the 256 MB Infinity Cache) give the same bytes per column as the
+             8192-column ones, so the traffic is HBM traffic.
+  flops    = (2 x FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions x 64 lanes per launch.
+Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 columns the value is per
+launch of one 32768-column chunk.
+usage: tools/make_traffic_json.py [round=r02]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r01"
-ncol = int(sys.argv[2]) if len(sys.argv) > 2 else 8192
-nlev = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
 
 
-def get(mode, counter):
+def get(fn, counter):
     out = {}
-    for line in open(os.path.join(ROOT, "profiles", "%s_pmc_%s_%s.txt" % (rnd, mode, counter))):
+    path = os.path.join(ROOT, "profiles", fn)
+    if not os.path.exists(path):
+        return out
+    for line in open(path):
         m = re.match(r"(.*?)\s+%s\s+dispatches\s+\d+\s+avg\s+(\S+)" % counter, line.strip())
         if m and "_solve_" in m.group(1):
             out[m.group(1).strip()] = float(m.group(2))
     return out
 
 
-traffic = {"_doc": __doc__.split("\n")[0] + " See tools/make_traffic_json.py."}
+traffic = {"_doc": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s_pmc_*; see tools/make_traffic_json.py" % rnd}
+flops = {"_doc": "FP64 flops per launch = (2 FMA + MUL + ADD + TRANS wave instructions) x 64 from profiles/%s_pmc_*_sq.txt; see tools/make_traffic_json.py" % rnd}
 for mode in ("clear", "cloudy"):
-    fetch, write = get(mode, "FETCH_SIZE"), get(mode, "WRITE_SIZE")
-    for k in fetch:
-        b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
-        if b > 1.0e6:
-            traffic["%s|%d|%d|%s" % (k, ncol, nlev, mode)] = b
+    for ncol, tag in ((8192, ""), (131072, "_131072")):
+        fetch, write = get("%s_pmc_%s_FETCH_SIZE%s.txt" % (rnd, mode, tag), "FETCH_SIZE"), get("%s_pmc_%s_WRITE_SIZE%s.txt" % (rnd, mode, tag), "WRITE_SIZE")
+        for k in fetch:
+            b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+            if b > 1.0e6:
+                traffic["%s|%d|60|%s" % (k, ncol, mode)] = b
+    sq = {c: get("%s_pmc_%s_sq.txt" % (rnd, mode), c) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")}
+    for k in sq["SQ_INSTS_VALU_FMA_F64"]:
+        f = 64.0 * (2.0 * sq["SQ_INSTS_VALU_FMA_F64"][k] + sq["SQ_INSTS_VALU_MUL_F64"].get(k, 0) + sq["SQ_INSTS_VALU_ADD_F64"].get(k, 0) + sq["SQ_INSTS_VALU_TRANS_F64"].get(k, 0))
+        if f > 1.0e6:
+            flops["%s|8192|60|%s" % (k, mode)] = f
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
+json.dump(flops, open(os.path.join(ROOT, "profiles", "fp64_flops.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1)); print(json.dumps(flops, indent=1))
