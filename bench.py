@@ -165,6 +165,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the McICA / end-to-end extras (N=1)")
+    ap.add_argument("--lw-first", action="store_true", help="enqueue the longwave before the shortwave (N=1; experiment)")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default) or torch.distributed")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
@@ -232,9 +233,12 @@ def main():
 
         def step():
             t = time.perf_counter()
+            if a.lw_first:
+                ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
             ctx.sw_fluxes(inp, mcica=cld, out=so, memspace=1)
             enq[0] += time.perf_counter() - t
-            ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
+            if not a.lw_first:
+                ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
             enq[1] += time.perf_counter() - t
             ctx.synchronize()
         for _ in range(warmup):

@@ -31,6 +31,36 @@ __global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
   const unsigned long long any = __ballot(cld);
   if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
 }
+// Preparation in ONE launch (see sw_prep_fused_kernel): phase 1 the layer part, layers strided over the 16 waves; phase 2
+// wave 0: the column scan (laytrop, precipitable water -> diffusivity angles) on the rows just written, and the tile's
+// cloud flag; phase 3, cloudy tiles only: cldprop / the rtrnmr overlap factors (one wave each, sequential in the layers as
+// the reference); with McICA the cldprmc band optics stay a launch of their own (see sw_prep_fused_kernel).
+#ifndef RRTMG_PREP_WAVES
+#define RRTMG_PREP_WAVES 16
+#endif
+constexpr int kPrepWaves = RRTMG_PREP_WAVES;
+__global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+  const bool act = col < d.ncol;
+  __shared__ int sh_cld;
+  if (act)
+    for (int l = w; l < d.nlay; l += kPrepWaves) lw_prep_layer(d, T, col, l);
+  __syncthreads();
+  if (w == 0) {
+    if (act) lw_prep_column(d, T, col);
+    bool cld = false;
+    if (act && d.icld >= 1 && d.cldfr)
+      for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(long)l * d.ncol + col] > 0.0;
+    const unsigned long long any = __ballot(cld);
+    if (lane == 0) { d.tile_cld[blockIdx.x] = any != 0ull; sh_cld = any != 0ull; }
+  }
+  if (!clouds) return;
+  __syncthreads();
+  if (!sh_cld || !act) return;
+  if (w == 0) lw_cloud_column(d, T, col);
+  if (w == kPrepWaves - 1 && maxrand) lw_mr_column(d, col);
+}
+
 __global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
   if (!d.tile_cld[blockIdx.x]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -127,6 +157,31 @@ __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T, int tile0
 __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
   if (col < d.ncol) lw_heat_layer(d, T, col, blockIdx.y);
+}
+// band integration AND heating rates in one launch (see sw_fluxheat_kernel)
+constexpr int kFluxLev = 8;
+__global__ void __launch_bounds__(64 * (kFluxLev + 1)) lw_fluxheat_kernel(LwDev d, LwTab T, int tile0) {
+  const int tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
+  const int col = tile * 64 + lane, lev = blockIdx.y * kFluxLev + j;
+  __shared__ double net[kFluxLev + 1][64], netc[kFluxLev + 1][64];
+  const bool act = col < d.ncol && lev <= d.nlay;
+  if (act) {
+    double f[6];
+    lw_flux_sums(d, col, lev, T.nitem, d.tile_cld[tile] != 0, f);
+    if (j < kFluxLev || lev == d.nlay) {
+      const long o = (long)lev * d.ncol + col;
+      d.uflx[o] = f[0]; d.dflx[o] = f[1]; d.uflxc[o] = f[2]; d.dflxc[o] = f[3];
+      if (d.idrv) { d.duflx_dt[o] = f[4]; d.duflxc_dt[o] = f[5]; }
+    }
+    net[j][lane] = f[0] - f[1]; netc[j][lane] = f[2] - f[3];
+  }
+  __syncthreads();
+  if (col < d.ncol && j < kFluxLev && lev < d.nlay) {
+    const long o0 = (long)lev * d.ncol + col;
+    const double dp = d.plev[o0] - d.plev[o0 + d.ncol];
+    d.hr[o0] = T.heatfac * (net[j][lane] - net[j + 1][lane]) / dp;
+    d.hrc[o0] = T.heatfac * (netc[j][lane] - netc[j + 1][lane]) / dp;
+  }
 }
 
 void free_lw_desc(rrtmg_ctx *ctx) {
@@ -257,12 +312,21 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     launch_interface_values(s, N, L, d.tlay, d.tsfc, d.play, d.plev, tl);
     d.tlev = tl;
   }
-  hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
-  hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
+  // RRTMG_HIP_UNFUSED (A/B; same results): bit 0 = separate preparation kernels, bit 1 = separate flux and heating-rate kernels
+  static const int unfused_bits = getenv("RRTMG_HIP_UNFUSED") ? atoi(getenv("RRTMG_HIP_UNFUSED")) : 0;
+  const bool unfused = unfused_bits & 1, unfused_flux = unfused_bits & 2;
+  if (unfused) {
+    hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
+    hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
+  } else {
+    hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0);
+  }
   if (clouds) {
     if (!d.mcica) {
-      hipLaunchKernelGGL(lw_cloud_kernel, gcol, blk, 0, s, d, T);
-      if (maxrand) hipLaunchKernelGGL(lw_mr_kernel, gcol, blk, 0, s, d);
+      if (unfused) {
+        hipLaunchKernelGGL(lw_cloud_kernel, gcol, blk, 0, s, d, T);
+        if (maxrand) hipLaunchKernelGGL(lw_mr_kernel, gcol, blk, 0, s, d);
+      }
     } else {
       hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);
       if (a->cldfmcl) {
@@ -301,10 +365,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       if (last) (void)hipEventRecord(ctx->ev[3][1], s);
     }
-    hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
+    if (unfused_flux) hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
+    else hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
   ctx->ev_valid[1] = true; ctx->ev_valid[3] = clouds;
-  hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
+  if (unfused_flux) hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
   if (ctx->deferred && a->memspace == 1) { ctx->pending[1] = true; ctx->status = 0; return RRTMG_OK; }

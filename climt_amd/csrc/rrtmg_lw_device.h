@@ -1302,9 +1302,9 @@ RRTMG_HD void lw_solve_item(const LwDev &d, const LwTab &T, int item, int col, d
 // one thread per (column, interface level)
 // nparts = number of work items (T.nitem); each partial is the sum over its item's g-points and already carries
 // wtdiff*delwave(band)
-RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts, bool cld) {
-  (void)T;
-  const int L = d.nlay, N = d.ncol;
+// out[0..5] = uflx, dflx, uflxc, dflxc, duflx_dt, duflxc_dt of (column, level), scaled by fluxfac
+RRTMG_HD void lw_flux_sums(const LwDev &d, int col, int lev, int nparts, bool cld, double *out) {
+  const int L = d.nlay;
   const int nk = d.idrv ? 6 : 4;
   const long st = (long)(L + 1) * d.pcols;
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
@@ -1318,9 +1318,16 @@ RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, in
     }
   }
   if (!cld) { t2 = t0; t3 = t1; t5 = t4; }   // the clear-sky variant wrote the total planes only (LwPartSink::dn_clear)
-  const long o = (long)lev * N + col;
-  d.uflx[o] = t0 * d.fluxfac; d.dflx[o] = t1 * d.fluxfac; d.uflxc[o] = t2 * d.fluxfac; d.dflxc[o] = t3 * d.fluxfac;
-  if (d.idrv) { d.duflx_dt[o] = t4 * d.fluxfac; d.duflxc_dt[o] = t5 * d.fluxfac; }
+  out[0] = t0 * d.fluxfac; out[1] = t1 * d.fluxfac; out[2] = t2 * d.fluxfac; out[3] = t3 * d.fluxfac;
+  out[4] = t4 * d.fluxfac; out[5] = t5 * d.fluxfac;
+}
+RRTMG_HD void lw_flux_level(const LwDev &d, const LwTab &T, int col, int lev, int nparts, bool cld) {
+  (void)T;
+  double f[6];
+  lw_flux_sums(d, col, lev, nparts, cld, f);
+  const long o = (long)lev * d.ncol + col;
+  d.uflx[o] = f[0]; d.dflx[o] = f[1]; d.uflxc[o] = f[2]; d.dflxc[o] = f[3];
+  if (d.idrv) { d.duflx_dt[o] = f[4]; d.duflxc_dt[o] = f[5]; }
 }
 // one thread per (column, layer)
 RRTMG_HD void lw_heat_layer(const LwDev &d, const LwTab &T, int col, int lay) {

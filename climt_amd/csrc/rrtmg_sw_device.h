@@ -1132,9 +1132,9 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // one thread per (column, interface level): g-point sum in reference order
 // pairs = false: the column's tile ran the clear-sky variant, slot c holds chunk c; true: the cloudy variant, one
 // slot per pair of g-points -- the chunk sums are formed here, so the summation order is the same.
-RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool pairs) {
-  const int L = d.nlay, N = d.ncol, P = d.pcols;
-  double fu = 0.0, fd = 0.0, cu = 0.0, cd = 0.0;
+RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, bool pairs, double &fu, double &fd, double &cu, double &cd) {
+  const int L = d.nlay, P = d.pcols;
+  fu = 0.0; fd = 0.0; cu = 0.0; cd = 0.0;
   const long st = (long)(L + 1) * P, slot = 4 * st;
   for (int c = 0; c < T.nitem[0]; ++c) {
     const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
@@ -1147,7 +1147,11 @@ RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bo
     }
   }
   if (!pairs) { cu = fu; cd = fd; }   // the clear-sky variant wrote the total planes only (SwPartSink::emit_clear)
-  const long o = (long)lev * N + col;
+}
+RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool pairs) {
+  double fu, fd, cu, cd;
+  sw_flux_sums(d, T, col, lev, pairs, fu, fd, cu, cd);
+  const long o = (long)lev * d.ncol + col;
   d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
 }
 // one thread per (column, layer): heating rates from the net-flux divergence
