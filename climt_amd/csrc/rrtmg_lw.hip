@@ -43,16 +43,30 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
+  // what the column scan reads back from the layer part -- [layer][coldry | h2o | lower flag][lane] -- and the per-wave cloud
+  // flags, in LDS (grids of up to kKeepLayers layers; deeper ones re-read the slab)
+  constexpr int kKeepLayers = 104;
+  __shared__ double sh_keep[kKeepLayers * 3 * 64];
+  __shared__ int sh_any[kPrepWaves];
+  const bool keep = d.nlay <= kKeepLayers;
+  bool cld = false;
   if (act)
-    for (int l = w; l < d.nlay; l += kPrepWaves) lw_prep_layer(d, T, col, l);
+    for (int l = w; l < d.nlay; l += kPrepWaves) {
+      lw_prep_layer(d, T, col, l, keep ? sh_keep + (3 * l) * 64 + lane : nullptr, 64);
+      if (d.icld >= 1 && d.cldfr) cld = cld || d.cldfr[(long)l * d.ncol + col] > 0.0;
+    }
+  {
+    const unsigned long long any = __ballot(cld);
+    if (lane == 0) sh_any[w] = any != 0ull;
+  }
   __syncthreads();
   if (w == 0) {
-    if (act) lw_prep_column(d, T, col);
-    bool cld = false;
-    if (act && d.icld >= 1 && d.cldfr)
-      for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(long)l * d.ncol + col] > 0.0;
-    const unsigned long long any = __ballot(cld);
-    if (lane == 0) { d.tile_cld[blockIdx.x] = any != 0ull; sh_cld = any != 0ull; }
+    if (act) lw_prep_column(d, T, col, keep ? sh_keep + lane : nullptr, 64);
+    if (lane == 0) {
+      int any = 0;
+      for (int k = 0; k < kPrepWaves; ++k) any |= sh_any[k];
+      d.tile_cld[blockIdx.x] = any; sh_cld = any;
+    }
   }
   if (!clouds) return;
   __syncthreads();
@@ -159,7 +173,7 @@ __global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
   if (col < d.ncol) lw_heat_layer(d, T, col, blockIdx.y);
 }
 // band integration AND heating rates in one launch (see sw_fluxheat_kernel)
-constexpr int kFluxLev = 8;
+constexpr int kFluxLev = 15;   // 16 waves per workgroup: the halo level is 1 in 16 of the partial-plane reads
 __global__ void __launch_bounds__(64 * (kFluxLev + 1)) lw_fluxheat_kernel(LwDev d, LwTab T, int tile0) {
   const int tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
   const int col = tile * 64 + lane, lev = blockIdx.y * kFluxLev + j;

@@ -100,7 +100,9 @@ RRTMG_HD size_t lw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) /
 // inatm (rrtmg_lw_rad.nomcica.f90:744-880) + setcoef indices (rrtmg_lw_setcoef.f90:253-411)
 // ------------------------------------------------------------------------------------------
 // layer part: one thread per (column, layer)
-RRTMG_HD void lw_prep_layer(const LwDev &d, const LwTab &T, int col, int l) {
+// keep (optional): keep[0] = coldry, keep[1] = h2o vmr, keep[2] = 1.0 if the layer is in the lower atmosphere -- what the column
+// part reads back, so that a fused kernel can hand it over in LDS
+RRTMG_HD void lw_prep_layer(const LwDev &d, const LwTab &T, int col, int l, double *keep = nullptr, int keep_stride = 0) {
   const int L = d.nlay, N = d.ncol;
   const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
   const double amd = 28.9660, amw = 18.0160;
@@ -184,11 +186,13 @@ RRTMG_HD void lw_prep_layer(const LwDev &d, const LwTab &T, int col, int l) {
     q[LP_COLDRY * 64] = coldry; q[LP_PAVEL * 64] = pavel;
     // bit 30: layer is in the lower atmosphere (counted into laytrop by the column part)
     q[LP_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 20) | (indminor << 24) | (laytrop << 30));
+    if (keep) { keep[0] = coldry; keep[keep_stride] = v1; keep[2 * keep_stride] = (double)laytrop; }
   }
 }
 
 // column part (after every layer of the column is done): laytrop, precipitable water -> diffusivity angle by band
-RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
+// kept (optional): the layers' (coldry, h2o, lower flag) as lw_prep_layer hands them out: kept[(3 l + k) * kept_stride]
+RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col, const double *kept = nullptr, int kept_stride = 0) {
   (void)T;
   const int L = d.nlay, N = d.ncol;
   const double amd = 28.9660, amw = 18.0160;
@@ -196,10 +200,16 @@ RRTMG_HD void lw_prep_column(const LwDev &d, const LwTab &T, int col) {
   double amttl = 0.0, wvttl = 0.0;
 #pragma unroll 8   // independent loads: keep several layers in flight
   for (int l = 0; l < L; ++l) {
-    const double *q = d.prep + lw_prep_off(L, col, l);
-    laytrop += ((int)q[LP_IDX * 64] >> 30) & 1;
-    const double coldry = q[LP_COLDRY * 64];
-    const double w1 = coldry * d.h2o[(long)l * N + col];
+    double coldry, h2o;
+    if (kept) {
+      coldry = kept[(3 * l) * kept_stride]; h2o = kept[(3 * l + 1) * kept_stride];
+      laytrop += (int)kept[(3 * l + 2) * kept_stride];
+    } else {
+      const double *q = d.prep + lw_prep_off(L, col, l);
+      laytrop += ((int)q[LP_IDX * 64] >> 30) & 1;
+      coldry = q[LP_COLDRY * 64]; h2o = d.h2o[(long)l * N + col];
+    }
+    const double w1 = coldry * h2o;
     amttl = amttl + coldry + w1;
     wvttl = wvttl + w1;
   }

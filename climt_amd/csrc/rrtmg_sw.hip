@@ -45,11 +45,12 @@ __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d,
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
+  __shared__ int sh_idx[256 * 64];   // the tile's packed index words [layer][lane]: the 14 band scans of phase 2 read them here
   if (act)
-    for (int l = w; l < d.nlay; l += kPrepWaves) sw_prep_layer(d, T, col, l);
+    for (int l = w; l < d.nlay; l += kPrepWaves) sh_idx[l * 64 + lane] = sw_prep_layer(d, T, col, l);
   __syncthreads();
   if (act)
-    for (int b = w; b < kSwNBand; b += kPrepWaves) sw_prep_column(d, T, col, b, b + 1);
+    for (int b = w; b < kSwNBand; b += kPrepWaves) sw_prep_column(d, T, col, b, b + 1, sh_idx + lane, 64);
   if (w == 0) {
     const unsigned long long any = __ballot(act && d.anycld[col] != 0);
     if (lane == 0) { d.tile_cld[blockIdx.x] = any != 0ull; sh_cld = any != 0ull; }
@@ -244,7 +245,7 @@ __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
 // planes of interface level l0 + j (the extra wave kFluxLev: the halo level on top, recomputed by the next workgroup, which
 // owns and stores it), the net fluxes meet in LDS, waves j < kFluxLev form the layer's heating rates from levels j and j + 1
 // -- the same differences of the same doubles as sw_heat_layer reads back from memory.
-constexpr int kFluxLev = 8;
+constexpr int kFluxLev = 15;   // 16 waves per workgroup: the halo level is 1 in 16 of the partial-plane reads
 __global__ void __launch_bounds__(64 * (kFluxLev + 1)) sw_fluxheat_kernel(SwDev d, SwTab T, int tile0) {
   const int tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
   const int col = tile * 64 + lane, lev = blockIdx.y * kFluxLev + j;

@@ -119,7 +119,8 @@ RRTMG_HD size_t sw_prep_size(int ncol, int nlay) { return (size_t)((ncol + 63) /
 // inatm_sw (rrtmg_sw_rad.nomcica.f90:1441-1465) + setcoef_sw (rrtmg_sw_setcoef.f90:137-303)
 // ------------------------------------------------------------------------------------------
 // layer part: one thread per (column, layer)
-RRTMG_HD void sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
+// returns the layer's packed index word (P_IDX) so that a caller can keep it at hand for the column part
+RRTMG_HD int sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
   const int L = d.nlay, N = d.ncol;
   const double *preflog = T.t + T.preflog, *tref = T.t + T.tref;
   const double amd = 28.9660, amw = 18.0160;
@@ -188,12 +189,14 @@ RRTMG_HD void sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
     q[P_COLH2O * 64] = colh2o; q[P_COLCO2 * 64] = colco2; q[P_COLO3 * 64] = colo3; q[P_COLCH4 * 64] = colch4;
     q[P_COLO2 * 64] = colo2; q[P_COLMOL * 64] = colmol;
     // bit 28: layer is in the lower atmosphere (counted into laytrop by the column part)
-    q[P_IDX * 64] = (double)(jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24) | (lower << 28));
+    const int packed = jp | (jt << 8) | (jt1 << 12) | (indself << 16) | (indfor << 24) | (lower << 28);
+    q[P_IDX * 64] = (double)packed;
     if (d.icld >= 1 && d.cldfr) {
       const double cf = d.cldfr[i];
       // rrtmg_sw_rad.nomcica.f90:616-620
       if (!d.mcica && cf > 1.e-6 && cf < 1.0 - 1.e-6) report_error(d.err, 10);
     }
+    return packed;
   }
 }
 
@@ -201,13 +204,15 @@ RRTMG_HD void sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
 // Bands b0 .. b1-1 of the solar-source bookkeeping; the column scalars (laytrop, cloud flag, clamped cos(zenith)) are
 // written by the caller that owns band 0.  The device runs one thread per (column, band) -- the per-band state
 // machines are ~500 instructions each, one thread for all 14 was the whole kernel time.
-RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col, int b0 = 0, int b1 = kSwNBand) {
+// idx: optional copy of the column's packed index words, idx[l * idx_stride] (the fused kernel's LDS copy); else the slab.
+RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col, int b0 = 0, int b1 = kSwNBand, const int *idx = nullptr, int idx_stride = 0) {
   (void)T;
   const int L = d.nlay, N = d.ncol;
   int laytrop = 0, anycld = 0;
+  auto packed = [&](int l) { return idx ? idx[l * idx_stride] : (int)d.prep[sw_prep_off(L, col, l) + P_IDX * 64]; };
 #pragma unroll 8   // independent loads: keep several layers in flight
   for (int l = 0; l < L; ++l) {
-    laytrop += ((int)d.prep[sw_prep_off(L, col, l) + P_IDX * 64] >> 28) & 1;
+    laytrop += (packed(l) >> 28) & 1;
     if (b0 == 0 && d.icld >= 1 && d.cldfr && d.cldfr[(long)l * N + col] > 0.0) anycld = 1;
   }
   if (b0 == 0) {
@@ -223,7 +228,7 @@ RRTMG_HD void sw_prep_column(const SwDev &d, const SwTab &T, int col, int b0 = 0
   // reference loops, result = last layer for which (lay == laysolfr) held.
   const int layreffr[kSwNBand] = {18, 30, 6, 3, 3, 8, 2, 6, 1, 2, 0, 32, 58, 49};
   const bool upper[kSwNBand] = {true, true, false, false, false, false, false, false, false, false, false, true, true, true};
-  auto jp_of = [&](int lay0) { return (int)d.prep[sw_prep_off(L, col, lay0) + P_IDX * 64] & 0xff; };
+  auto jp_of = [&](int lay0) { return packed(lay0) & 0xff; };
   for (int b = b0; b < b1; ++b) {
     // one pass over the layers with a sliding (previous, current, next) window of jp
     const int ref = layreffr[b];
