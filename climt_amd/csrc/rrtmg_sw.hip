@@ -194,10 +194,17 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
   // launch order: tile groups, within a group the items heaviest first -- the group's prep rows (12 tiles x 0.46 MB) are
   // fetched while its 56 items run, instead of the whole prep slab once per item
   const int q = blockIdx.x;
-#if RRTMG_SWC_XCD
-  // XCD-aware order (speed only): block q is observed to run on XCD q % 8, each XCD with its own 4 MB L2.  Tile group g is
-  // given to XCD g % 8 and its items run there one after the other, so the group's prep rows are fetched into ONE L2 and
-  // shared by the items in flight, instead of being fetched by all eight.
+#if RRTMG_SWC_XCD == 2
+  // XCD-aware order (speed only): block q is observed to run on XCD q % 8, each XCD with its own 4 MB L2.  The group-major
+  // sequence s = group * nitem + k is cut into eight equal contiguous runs, one per XCD (nitem = 56 is a multiple of 8, so
+  // the cut is exact): every XCD gets the same number of workgroups, and a tile group's prep rows are fetched into one L2
+  // (two where a run boundary falls inside the group) instead of all eight.
+  const int per = (int)(gridDim.x >> 3);
+  const int sidx = (q & 7) * per + (q >> 3);
+  const int ctile0 = (sidx / T.nitem[1]) * kSwCldWgWaves, k = sidx % T.nitem[1];
+#elif RRTMG_SWC_XCD
+  // (first attempt, kept as a switch: whole tile groups dealt round-robin to the XCDs -- unbalanced unless the group
+  // count is a multiple of 8: measured slower at 8192 columns)
   const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
   const int grp = ((q >> 3) / T.nitem[1]) * 8 + (q & 7), k = (q >> 3) % T.nitem[1];
   if (grp >= ngrp) return;
@@ -499,7 +506,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     if (clouds) {
       if (last) (void)hipEventRecord(ctx->ev[2][0], s);
       const int cgrp = (nt + kSwCldWgWaves - 1) / kSwCldWgWaves;
-      const int cgrid = (RRTMG_SWC_XCD ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
+      const int cgrid = (RRTMG_SWC_XCD == 1 ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
       hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
       if (last) (void)hipEventRecord(ctx->ev[2][1], s);
     }
