@@ -1001,11 +1001,22 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; cldrad[g] = 0.0; clrrad[g] = 0.0; radmr[g] = 0.0; }
   if constexpr (CLD) sink.dn(L, 0.0, 0.0); else sink.dn_clear(L, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
+#ifdef RRTMG_LW_PREFETCH
+  LwLayerIn s_next;
+  lw_load_layer(d, col, L - 1, s_next);
+#endif
   for (int lev = L; lev >= 1; --lev) {
     const int l = lev - 1;
     const long i = (long)l * N + col;
+#ifdef RRTMG_LW_PREFETCH
+    // experiment: the next layer's prep rows are requested before this layer's arithmetic starts (one layer of software
+    // pipelining: hides the L2 latency of the rows at the price of a second LwLayerIn in registers)
+    const LwLayerIn s = s_next;
+    if (lev > 1) lw_load_layer(d, col, l - 1, s_next);
+#else
     LwLayerIn s;
     lw_load_layer(d, col, l, s);
+#endif
     V<G> plfrac;
 #ifdef RRTMG_ABL_NOTAUG
     plfrac = vsplat<G>(0.1); const V<G> taug = vsplat<G>(s.colh2o * 1.0e-3 + s.fac00);

@@ -172,6 +172,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   sw_solve_item<CLD, kLdsK>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
 
+#if !RRTMG_SWC_G4   // the round-1 kernel for the cloudy tiles, kept as a build switch (RRTMG_SWC_G4=0)
 // The cloudy tiles: both sky streams per g-point need ~170 VGPRs, which does not go with the 128-VGPR cap of the clear-sky
 // kernel's 4 waves/SIMD (spills: measured +30 %): 3 waves/SIMD here.  Workgroup = 12 wavefronts = the same pair of
 // g-points for 12 consecutive tiles, one workgroup per CU, sharing in LDS the transmittance table (80 KB) and the pair's
@@ -190,7 +191,7 @@ constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
 #ifndef RRTMG_SWC_XCD
 #define RRTMG_SWC_XCD 0
 #endif
-__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
+__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_pairs_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   // launch order: tile groups, within a group the items heaviest first -- the group's prep rows (12 tiles x 0.46 MB) are
   // fetched while its 56 items run, instead of the whole prep slab once per item
   const int q = blockIdx.x;
@@ -239,6 +240,43 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
+
+#endif
+
+#if RRTMG_SWC_G4
+// The cloudy tiles (flagged by the preparation kernel): both sky streams per g-point.  They run the CLEAR kernel's item set
+// -- chunks of 4 g-points, so the item-invariant work (layer state, species mixtures, weights, row indices) is paid once per
+// 4 g-points, not per pair -- at 2 waves/SIMD: 238 VGPRs, no spills; 8-wave workgroups, one per CU, sharing the
+// transmittance table and the chunk's slice in LDS.  Against the round-1 kernel (pairs, 170 VGPRs, 3 waves/SIMD, 12-wave
+// workgroups): 1.91 -> 1.73 ms at 8192 columns; the partial sums still leave per PAIR, so results are bit-identical.
+constexpr int kC4Waves = 8;
+__global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
+  const int ngrp = (ntile + kC4Waves - 1) / kC4Waves;
+  const int q = blockIdx.x, ctile0 = (q % ngrp) * kC4Waves, k = q / ngrp;
+  {
+    bool mine = false;
+    for (int w = 0; w < kC4Waves; ++w)
+      if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
+    if (!mine) return;
+  }
+  if (d.only_item >= 0 && k != d.only_item) return;
+  const int id = T.sched[0][k], item = T.item[0][id], slot = item_iw0(item) >> 1;
+  __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
+  sw_stage_slice(T, item, sh_k, 64 * kC4Waves);
+  __shared__ double sh_exp[kExpTblN];
+  for (int i = threadIdx.x; i < kExpTblN; i += 64 * kC4Waves) sh_exp[i] = T.t[T.exp_tbl + i];
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ctile = ctile0 + wave, tile = tile0 + ctile;
+  if (ctile >= ntile || !d.tile_cld[tile]) return;
+  const int lane = threadIdx.x & 63;
+  const int col = tile * 64 + lane;
+  if (col >= d.ncol) return;
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + lane * item_g(item);
+  SwPartSink sink = sw_part_sink(d, slot, col);
+  sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
+}
+#endif
 
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T, int tile0) {
   const int tile = tile0 + blockIdx.x, col = tile * 64 + threadIdx.x;
@@ -505,9 +543,15 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     if (last) (void)hipEventRecord(ctx->ev[0][1], s);
     if (clouds) {
       if (last) (void)hipEventRecord(ctx->ev[2][0], s);
+#if !RRTMG_SWC_G4
       const int cgrp = (nt + kSwCldWgWaves - 1) / kSwCldWgWaves;
       const int cgrid = (RRTMG_SWC_XCD == 1 ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
-      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
+#endif
+#if RRTMG_SWC_G4
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem[0]), dim3(64 * kC4Waves), 0, s, d, T, t0, nt);
+#else
+      hipLaunchKernelGGL(sw_solve_cloudy_pairs_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
+#endif
       if (last) (void)hipEventRecord(ctx->ev[2][1], s);
     }
     if (unfused_flux) hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);

@@ -1105,7 +1105,10 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 template <int BAND, bool CLD, bool LDSK, class Sink>
 RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = SwBandCfg<BAND>::ng;
-  if constexpr (!CLD && ng >= 4) {   // chunks of 4 exist in item set 0 (clear sky) only
+#ifndef RRTMG_SWC_G4
+#define RRTMG_SWC_G4 1      // cloudy tiles in chunks of 4 g-points too (sw_solve_cloudy_kernel at 2 waves/SIMD); 0: pairs at 3 waves/SIMD
+#endif
+  if constexpr ((!CLD || RRTMG_SWC_G4) && ng >= 4) {   // chunks of 4 exist in item set 0 (clear sky) only
     if (g == 4) { sw_solve_thread<BAND, 4, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb); return; }
   }
   if constexpr (CLD || ng % 4 != 0) sw_solve_thread<BAND, 2, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb);
