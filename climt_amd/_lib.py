@@ -146,10 +146,16 @@ class Context:
         self._ck(self.lib.rrtmg_hip_set_constants(self.h, *[float(k[n]) for n in CONSTANT_NAMES]))
 
     def sw_init(self, cpdair, blob=None):
-        self._ck(self.lib.rrtmg_hip_sw_init(self.h, float(cpdair), (blob or SW_DATA).encode()))
+        key = ("sw", float(cpdair), blob or SW_DATA)
+        if getattr(self, "_sw_key", None) != key:       # (components sharing the context initialise the tables once)
+            self._ck(self.lib.rrtmg_hip_sw_init(self.h, float(cpdair), (blob or SW_DATA).encode()))
+            self._sw_key = key
 
     def lw_init(self, cpdair, blob=None):
-        self._ck(self.lib.rrtmg_hip_lw_init(self.h, float(cpdair), (blob or LW_DATA).encode()))
+        key = ("lw", float(cpdair), blob or LW_DATA)
+        if getattr(self, "_lw_key", None) != key:
+            self._ck(self.lib.rrtmg_hip_lw_init(self.h, float(cpdair), (blob or LW_DATA).encode()))
+            self._lw_key = key
 
     def lw_tables_synthetic(self):
         return bool(self.lib.rrtmg_hip_lw_tables_synthetic(self.h))

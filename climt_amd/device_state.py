@@ -162,9 +162,7 @@ class DeviceState(dict):
         return q
 
     def init_tables(self, which, cpd):
-        if which not in self._tables:
-            (self.ctx.sw_init if which == "sw" else self.ctx.lw_init)(cpd)
-            self._tables.add(which)
+        (self.ctx.sw_init if which == "sw" else self.ctx.lw_init)(cpd)      # (idempotent per context)
 
     # ---- back to the host ----------------------------------------------------------------------------------------
     def download(self, name, synchronize=True):

@@ -30,9 +30,15 @@ def physical_constants():
     return dict(zip(CONSTANT_NAMES, vals))
 
 
+_shared = {}
+
+
 def make_context(device):
-    """A librrtmg_hip context with the constants set.  Per-instance (the reference keeps flags and
-    tables in process-global Cython/Fortran state: SURVEY.md A.5)."""
-    ctx = Context(device)
-    ctx.set_constants(**physical_constants())
+    """The librrtmg_hip context of `device` with the constants set -- ONE per device, shared by every component of the
+    process (tables, streams and work buffers once, not once per component instance; the reference likewise keeps one set of
+    module-global tables).  Flags travel with each call, so sharing is invisible to the components."""
+    ctx = _shared.get(device)
+    if ctx is None or not getattr(ctx, "h", None):
+        ctx = _shared[device] = Context(device)
+        ctx.set_constants(**physical_constants())
     return ctx

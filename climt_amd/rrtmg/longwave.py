@@ -107,7 +107,6 @@ class RRTMGLongwave(TendencyComponent):
             msg = ("RRTMGLongwave: the longwave k-distribution tables in this build are SYNTHETIC (the reference data "
                    "file rrtmg_lw_k_g.f90 was not available); fluxes and heating rates are not physical.")
             if not (allow_synthetic_tables or os.environ.get("RRTMG_HIP_ALLOW_SYNTHETIC_LW", "") not in ("", "0")):
-                self._ctx.close()
                 raise RuntimeError(msg + "  Pack the real tables (tools/pack_tables.py lw) or pass allow_synthetic_tables=True "
                                          "/ set RRTMG_HIP_ALLOW_SYNTHETIC_LW=1 to run on them knowingly.")
             logging.warning(msg)

@@ -316,6 +316,13 @@ def test_mixed_clear_and_cloudy_tiles_ragged(gpu_ctx, mcica):
     sw, lw = gpu_ctx.sw_fluxes(c, mcica=mcica), gpu_ctx.lw_fluxes(c, mcica=mcica)
     _check(sw, emu.sw_fluxes(c, mcica=mcica))
     _check(lw, emu.lw_fluxes(c, mcica=mcica))
+    from oracle import ref_driver
+    if ref_driver.available("sw") and ref_driver.available("lw"):      # and against the reference Fortran itself
+        from helpers import live_oracle
+        cr = {k: v for k, v in c.items() if k != "lat"}
+        rsw, rlw, kind = live_oracle(cr, mcica, chunk=100, procs=3)
+        _check(sw, rsw)
+        _check(lw, rlw)
     # the clear columns of the mixed tile (cloudy variant) against the same columns in an all-clear call (clear variant)
     sub = {k: (np.ascontiguousarray(v[..., 256:280]) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
     sw2, lw2 = gpu_ctx.sw_fluxes(sub, mcica=mcica), gpu_ctx.lw_fluxes(sub, mcica=mcica)
@@ -337,8 +344,16 @@ def test_edge_shapes_against_emulation(gpu_ctx, ncol, nlay):
         c["cldfr"][1:3] = 0.5; c["cliqwp"][1:3] = 40.0; c["cicewp"][1:3] = 0.0
     emu = EmuContext()
     # (GPU: fused multiply-adds, host emulation: none -- the round-off gap grows with the layer count)
-    _check(gpu_ctx.sw_fluxes(c, mcica=True), emu.sw_fluxes(c, mcica=True), tight=5.0e-8)
-    _check(gpu_ctx.lw_fluxes(c, mcica=True), emu.lw_fluxes(c, mcica=True), tight=5.0e-8)
+    gsw, glw = gpu_ctx.sw_fluxes(c, mcica=True), gpu_ctx.lw_fluxes(c, mcica=True)
+    _check(gsw, emu.sw_fluxes(c, mcica=True), tight=5.0e-8)
+    _check(glw, emu.lw_fluxes(c, mcica=True), tight=5.0e-8)
+    from oracle import ref_driver
+    if ref_driver.available("sw") and ref_driver.available("lw"):      # and against the reference Fortran itself
+        from helpers import live_oracle
+        c.pop("lat", None)
+        rsw, rlw, kind = live_oracle(c, True, chunk=64, procs=4)
+        _check(gsw, rsw, tight=5.0e-8)
+        _check(glw, rlw, tight=5.0e-8)
 
 
 def test_argument_errors(gpu_ctx):
