@@ -355,6 +355,7 @@ def main():
         else:
             kname, kms, bpc = "rrtmg::lw_solve_all_kernel" + ("<true, false>" if cloudy else "<false, false>"), lw_ms, (56 * L + 22) * 8
         achieved = bpc * N / (kms * 1e-3) / 1e9
+        kms_serial = float(np.mean(r["ssw"] if sw_ms >= lw_ms else r["slw"]))      # the same kernel with the GPU to itself
         key = "%s|%d|%d|%s" % (kname, N, L, "cloudy" if cloudy else "clear")
         traffic = _profile_json("hbm_traffic.json").get(key)
         flops = _profile_json("fp64_flops.json").get(key)      # FP64 flops per launch from the SQ instruction counters
@@ -378,7 +379,9 @@ def main():
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms,
                          "algorithmic_bytes_per_column": bpc, "sw_solve_ms": sw_ms, "lw_solve_ms": lw_ms,
                          "sw_solve_ms_serial": float(np.mean(r["ssw"])), "lw_solve_ms_serial": float(np.mean(r["slw"])),
+                         "kernel_ms_serial": kms_serial, "frac_serial": bpc * N / (kms_serial * 1e-3) / HBM_PEAK,
                          "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
+                         "fp64_frac_serial": (flops / (kms_serial * 1e-3) / FP64_PEAK) if flops else None,
                          "host_call_ms": {"sw": r["enq_sw"], "sw+lw": r["enq"]},
                          "note": "achieved/frac: ALGORITHMIC bytes over the event-timed duration in the timed region (SW and LW kernels overlap "
                                  "there); `traffic` = measured HBM bytes per launch and `fp64_flops_per_launch` = measured FP64 flops per launch "
