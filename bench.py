@@ -249,16 +249,19 @@ def main():
             step()
         _hip.synchronize()
         enq[0] = enq[1] = 0.0
-        per, ksw, klw = [], [], []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            t = time.perf_counter()
-            step()
-            per.append((time.perf_counter() - t) * 1e3)
-            ksw.append(ctx.kernel_ms("sw", cloudy=cld))
-            klw.append(ctx.kernel_ms("lw", cloudy=cld))
-        _hip.synchronize()
-        ms = (time.perf_counter() - t0) * 1e3 / steps
+        per, ksw, klw, brackets = [], [], [], []
+        for _ in range(reps_of(steps, ncol, nlay, cld)):      # EXACTLY `steps` steps per bracket; brackets repeated to >= 1 s
+            _hip.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t = time.perf_counter()
+                step()
+                per.append((time.perf_counter() - t) * 1e3)
+                ksw.append(ctx.kernel_ms("sw", cloudy=cld))
+                klw.append(ctx.kernel_ms("lw", cloudy=cld))
+            _hip.synchronize()
+            brackets.append((time.perf_counter() - t0) * 1e3 / steps)
+        ms = float(np.median(brackets))
         ctx.set_deferred(False)
         ssw, slw = [], []
         for _ in range(3):      # kernel durations without the SW||LW overlap, for reference
@@ -266,7 +269,13 @@ def main():
             ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
             ssw.append(ctx.kernel_ms("sw", cloudy=cld))
             slw.append(ctx.kernel_ms("lw", cloudy=cld))
-        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / steps, enq=enq[1] * 1e3 / steps, c=c)
+        n_all = max(1, len(per))
+        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets)
+
+    def reps_of(k, ncol, nlay, cld):
+        """Brackets of exactly k steps needed for >= 1 s of timed region (1 when k was chosen by pick_steps)."""
+        est = ncol * (nlay / 60.0) / (2.0e6 if cld else 4.0e6)
+        return int(max(1, min(400, np.ceil(1.2 / (k * est)))))
 
     def pick_steps(ncol, nlay, cld):
         """Enough steps for >= 1 s of timed region (estimated from the large-grid rates of DESIGN.md 5)."""
@@ -328,20 +337,22 @@ def main():
         for _ in range(warmup):
             step()
         fence()
-        per, ksw, klw = [], [], []
-        t0 = time.perf_counter()
-        for _ in range(steps):
-            t = time.perf_counter()
-            step()
-            per.append((time.perf_counter() - t) * 1e3)
-            ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
-            klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
-        fence()
-        ms = (time.perf_counter() - t0) * 1e3 / steps
-        t = torch.tensor([ms], dtype=torch.float64, device="cuda:%d" % local)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        ms = float(t.item())
-        r = dict(ksw=ksw, klw=klw, ssw=ksw, slw=klw, enq_sw=0.0, enq=0.0)
+        per, ksw, klw, brackets = [], [], [], []
+        for _ in range(reps_of(steps, N, L, cloudy)):      # EXACTLY `steps` steps per bracket (barrier + sync on both sides)
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                t = time.perf_counter()
+                step()
+                per.append((time.perf_counter() - t) * 1e3)
+                ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
+                klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
+            fence()
+            t = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], dtype=torch.float64, device="cuda:%d" % local)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's bracket
+            brackets.append(float(t.item()))
+        ms = float(np.median(brackets))
+        r = dict(ksw=ksw, klw=klw, ssw=ksw, slw=klw, enq_sw=0.0, enq=0.0, brackets=brackets)
         if gather_error:
             comm_note += "output gather FAILED and was switched off (%s); " % gather_error[0]
     value = world * N / (ms * 1e-3)
@@ -372,7 +383,9 @@ def main():
                        "columns_per_gpu": N, "levels": L, "parallelism": par,
                        "communicator": (comm_note + comm_kind) if comm_kind else None,
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
-                       "timed_region_s": ms * steps * 1e-3, "ms_per_step_median": float(np.median(per)),
+                       "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
+                       "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
+                       "ms_per_step_median": float(np.median(per)),
                        "ms_per_step_p10_p90": [float(np.percentile(per, 10)), float(np.percentile(per, 90))],
                        "lw_k_tables": "synthetic (reference LW data file missing)", "sw_k_tables": "reference"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",

@@ -148,7 +148,7 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   {
     const LwBandTab &B = T.b[item & 0xff];
     const double *src = T.t + B.slab + ig0;
-    const int ng = B.ng, sh = g == 4 ? 2 : 1, n = B.nrows << sh;
+    const int ng = B.ng, sh = g == 8 ? 3 : g == 4 ? 2 : 1, n = B.nrows << sh;
     for (int i = threadIdx.x; i < n; i += 64 * kLwWgWaves) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
   }
   __syncthreads();

@@ -42,6 +42,9 @@ constexpr int kLwMaxItem = 72;
 #ifndef RRTMG_LW_GMAX
 #define RRTMG_LW_GMAX 4
 #endif
+#ifndef RRTMG_LW_G8
+#define RRTMG_LW_G8 0      // experiment: 8 g-points per thread in the bands without a binary species mixture
+#endif
 
 struct LwTab {
   const double *t;
@@ -1198,7 +1201,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 #ifndef RRTMG_LW_KU
 #define RRTMG_LW_KU 4
 #endif
-  constexpr int kU = RRTMG_LW_KU;
+  constexpr int kU = G == 8 ? 2 : RRTMG_LW_KU;
   for (int lev0 = 1; lev0 <= L; lev0 += kU) {
     V<G> r_atrans[kU], r_bbugas[kU];
 #pragma unroll
@@ -1290,6 +1293,10 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 template <int BAND, bool CLD, bool MR, bool LDSK, class Sink>
 RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = kLwNg[BAND - 1];
+  constexpr bool simple = BAND == 1 || BAND == 2 || BAND == 6 || BAND == 8 || BAND == 10 || BAND == 11 || BAND == 14;
+  if constexpr (RRTMG_LW_G8 && simple && ng >= 8) {
+    if (g == 8) { lw_solve_thread<BAND, 8, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb); return; }
+  }
   if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
     if (g == 4) { lw_solve_thread<BAND, 4, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb); return; }
   }
