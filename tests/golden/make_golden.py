@@ -330,6 +330,25 @@ def reference_option_cases():
         np.savez_compressed(os.path.join(OUT, "ref_opt_%s.npz" % name), **save)
         print("option case", name, {k: float(np.abs(r[k]).max()) for k in keys[:2]})
 
+
+def cache_outputs_only(cls, desc):
+    """climt_cacheout_<Class>-<desc>.npz: the expected outputs of a reference cache whose input state is a missing blob
+    (`*_stepping-1.cache` absent: .MISSING_LARGE_BLOBS) but is the plain default state of the reference's test
+    (tests/test_components.py:250-255: get_default_state([component], get_grid(nx=32, ny=16, nz=28))), which
+    climt_amd.get_default_state reproduces (pinned by the other caches).  Tendencies, diagnostics, and the diagnostics of the
+    10 s Adams-Bashforth step (`*_stepping-0.cache`)."""
+    save = {}
+    for grp, fn in (("tend", "%s-%s-0.cache"), ("diag", "%s-%s-1.cache"), ("stepdiag", "%s-%s_stepping-0.cache")):
+        path = fn % (cls, desc)
+        if not os.path.exists(os.path.join(CACHE, path)):
+            continue
+        for k, (v, d, u) in read_cache(path).items():
+            save["%s/%s/values" % (grp, k)] = v
+            save["%s/%s/dims" % (grp, k)] = np.array(",".join(d))
+            save["%s/%s/units" % (grp, k)] = np.array(u)
+    np.savez_compressed(os.path.join(OUT, "climt_cacheout_%s-%s.npz" % (cls, desc)), **save)
+    print("cache outputs", cls, desc, len(save))
+
 if __name__ == "__main__":
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
@@ -344,3 +363,5 @@ if __name__ == "__main__":
     berger_cases()
     slab_surface_cases()
     reference_option_cases()
+    for cls in ("TestRRTMGShortwave", "TestRRTMGLongwave"):
+        cache_outputs_only(cls, "3d")

@@ -212,3 +212,40 @@ def test_committed_bench_lines_carry_the_contract_fields():
         c = j["cpu_baseline"]
         assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "columns/s" and c["sample"]
         assert abs(j["value"] - j["n_gpus"] * n / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+
+
+def _cacheout(cls):
+    z = np.load(os.path.join(GOLDEN, "climt_cacheout_%s-3d.npz" % cls))
+    out = {"tend": {}, "diag": {}, "stepdiag": {}}
+    for k in z.files:
+        grp, name, what = k.split("/")
+        out[grp].setdefault(name, {})[what] = z[k]
+    return out
+
+
+def check_3d_cache_from_generated_state(cls):
+    """The reference's 32 x 16 x 28 cache classes whose stored input state is a missing blob: the state is the plain default
+    state of its test (tests/test_components.py:250-255), rebuilt by climt_amd.get_default_state; outputs of the call and the
+    diagnostics of the 10 s Adams-Bashforth step against the caches at the reference's 1e-8 (longwave: once the tables are real)."""
+    import datetime as dtm
+    comp = climt_amd.RRTMGShortwave() if cls == "TestRRTMGShortwave" else climt_amd.RRTMGLongwave(allow_synthetic_tables=True)
+    tol = 1e-8 if cls == "TestRRTMGShortwave" or not comp._ctx.lw_tables_synthetic() else None
+    exp = _cacheout(cls)
+    state = climt_amd.get_default_state([comp], grid_state=climt_amd.get_grid(nx=32, ny=16, nz=28))
+    t, d = comp(state)
+    stepd, _ = climt_amd.AdamsBashforth(comp)(state, dtm.timedelta(seconds=10))
+    n = 0
+    for got, want in ((t, exp["tend"]), (d, exp["diag"]), (stepd, exp["stepdiag"])):
+        assert set(want) <= set(got)
+        for k, w in want.items():
+            dims = tuple(x for x in str(w["dims"]).split(",") if x)
+            g = np.transpose(got[k].values, [got[k].dims.index(x) for x in dims])
+            assert g.shape == w["values"].shape and not np.isnan(g).any()
+            assert tol is None or maxdiff(g, w["values"]) <= tol, (cls, k, maxdiff(g, w["values"]))
+            n += 1
+    assert n >= 12
+
+
+@pytest.mark.parametrize("cls", ["TestRRTMGShortwave", "TestRRTMGLongwave"])
+def test_3d_caches_from_generated_default_state(cls):
+    check_3d_cache_from_generated_state(cls)

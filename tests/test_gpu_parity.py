@@ -785,3 +785,11 @@ def test_radiation_column_example_runs_in_both_modes():
     for a, b in zip(*outs):
         va, vb = [float(x) for x in re.findall(r"-?\d+\.\d+", a)], [float(x) for x in re.findall(r"-?\d+\.\d+", b)]
         np.testing.assert_allclose(va, vb, rtol=0, atol=2e-3)      # printed to 2-3 decimals
+
+
+@pytest.mark.parametrize("cls", ["TestRRTMGShortwave", "TestRRTMGLongwave"])
+def test_3d_reference_caches_from_generated_default_state(cls):
+    """TestRRTMG{Shortwave,Longwave}-3d-{0,1}.cache and -3d_stepping-0.cache (32 x 16 x 28) on the GPU, from a state built by
+    get_grid / get_default_state (the caches' own input-state file is a missing blob); see tests/test_components_host.py."""
+    from test_components_host import check_3d_cache_from_generated_state
+    check_3d_cache_from_generated_state(cls)
