@@ -169,6 +169,7 @@ def main():
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default) or torch.distributed")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
+    ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (2 ranks on a 1-GPU box; with --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (communicator, gather) with a single rank too")
     a = ap.parse_args()
     preset = {2: (8192, 60, False), 3: (8192, 60, True), 4: (16384, 60, True), 5: (129600, 100, True)}[a.config]
@@ -180,7 +181,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    local = 0 if "--share-device" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or a.force_dist
     if world > 1:
         a.gpus = world
