@@ -793,3 +793,27 @@ def test_3d_reference_caches_from_generated_default_state(cls):
     get_grid / get_default_state (the caches' own input-state file is a missing blob); see tests/test_components_host.py."""
     from test_components_host import check_3d_cache_from_generated_state
     check_3d_cache_from_generated_state(cls)
+
+
+@pytest.mark.parametrize("mode", ["all", "root", "none"])
+def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
+    """climt_amd.distributed.ShardedRadiation on the device with RcclComm (librccl bound through ctypes, its own stream,
+    device-side ordering after the kernels): one rank, collective forced, three steps so that both halves of the double
+    buffer are gathered -- against the plain device call.  (Multi-rank logic: world-size-2 gloo test on CPU.)"""
+    from climt_amd.distributed import RcclComm, ShardedRadiation
+    from climt_amd.synthetic import make_columns
+    N, L = 1000, 40
+    c = make_columns(N, L, cloudy=True, seed=8); c.pop("lat"); c.update(BASE); c.update(irng=0, permuteseed=21, icld=2)
+    want = dict(gpu_ctx.sw_fluxes(c, mcica=True)); want.update(gpu_ctx.lw_fluxes(c, mcica=True))
+    comm = RcclComm(0, 1, 0)
+    try:
+        sr = ShardedRadiation(gpu_ctx, comm, N, L, gather=mode, force=True)
+        sr.set_inputs(c)
+        for _ in range(3):
+            b = sr.step(mcica=True)
+        sr.finish()
+        got = sr.gathered_host(b)
+        assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    finally:
+        gpu_ctx.set_deferred(False)
+        comm.close()
