@@ -195,6 +195,9 @@ def main():
         # dmabuf IPC for the peer mappings (the host driver supports nothing else)
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # torch's process group creates streams of its own before the context creates its two: with the runtime's default of
+        # four hardware queues the SW and LW streams then share one and the step loses its overlap (2.00 vs 1.76 ms)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
         torch.cuda.set_device(local)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -299,10 +302,30 @@ def main():
                 box = [payload]
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
-            try:
-                comm = RcclComm(rank, world, local, broadcast=bcast)
-            except Exception as e:
-                comm_note = "librccl via ctypes failed (%s: %s); " % (type(e).__name__, str(e)[:160])
+            # communicator + one small all-gather end to end, under a watchdog: a bootstrap that never returns must cost
+            # a fallback to torch.distributed, not the run
+            import threading
+            box = {}
+
+            def bring_up():
+                try:
+                    torch.cuda.set_device(local)      # (the current device is per thread)
+                    c = RcclComm(rank, world, local, broadcast=bcast)
+                    src, dst = _hip.DeviceArray((8,)), _hip.DeviceArray((8 * world,))
+                    c.all_gather(src.ptr, dst.ptr, 8)
+                    c.wait()
+                    box["comm"] = c
+                except Exception as e:
+                    box["err"] = e
+            th = threading.Thread(target=bring_up, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("RRTMG_BENCH_RCCL_TIMEOUT", "240")))
+            if "comm" in box:
+                comm = box["comm"]
+            elif "err" in box:
+                comm_note = "librccl via ctypes failed (%s: %s); " % (type(box["err"]).__name__, str(box["err"])[:160])
+            else:
+                comm_note = "librccl via ctypes did not come up within its time limit; "
             ok = torch.tensor([1 if comm is not None else 0], device="cuda:%d" % local)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # all ranks or none
             if int(ok.item()) == 0:
