@@ -122,6 +122,80 @@ template <int G> RRTMG_HD void vstore(double *p, const V<G> &x) {
   _Pragma("unroll") for (int i = 0; i < G; ++i) p[i] = x.v[i];
 }
 
+// Scratch-slab rows of the solve kernels: the G values of one (layer, field) for the 64 lanes of a tile.
+// RRTMG_SCR_PAIRMAJOR = 0: [lane][G] (a lane's G values contiguous: two 16-byte accesses 32 bytes apart for G = 4);
+// 1: [G/2][lane][2] (each 16-byte access of the wave is one contiguous 1 KB run).  p -> this lane's first element
+// (slab row + lane * G, resp. lane * 2), stride = lanes per row.  RRTMG_SCR_NT: non-temporal accesses (the slab is written
+// once and read once, a whole sweep later).
+#ifndef RRTMG_SCR_PAIRMAJOR
+#define RRTMG_SCR_PAIRMAJOR 1
+#endif
+#ifndef RRTMG_SCR_NT
+#define RRTMG_SCR_NT 1
+#endif
+template <int G> RRTMG_HD long scr_lane_offset(int lane) { return (RRTMG_SCR_PAIRMAJOR && G % 2 == 0) ? (long)lane * 2 : (long)lane * G; }
+template <int G> RRTMG_HD V<G> scr_load(const double *p, long stride) {
+  V<G> r;
+  if constexpr (G % 2 == 0) {
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) {
+      const double *q = p + (RRTMG_SCR_PAIRMAJOR ? (long)(i / 2) * stride * 2 : (long)i);
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef double d2 __attribute__((ext_vector_type(2)));
+#if RRTMG_SCR_NT
+      const d2 x = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(q));
+#else
+      const d2 x = *reinterpret_cast<const d2 *>(q);
+#endif
+      r.v[i] = x.x; r.v[i + 1] = x.y;
+#else
+      r.v[i] = q[0]; r.v[i + 1] = q[1];
+#endif
+    }
+  } else {
+    _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = p[i];
+  }
+  return r;
+}
+template <int G> RRTMG_HD void scr_store(double *p, long stride, const V<G> &x) {
+  if constexpr (G % 2 == 0) {
+    _Pragma("unroll") for (int i = 0; i < G; i += 2) {
+      double *q = p + (RRTMG_SCR_PAIRMAJOR ? (long)(i / 2) * stride * 2 : (long)i);
+#if defined(__HIP_DEVICE_COMPILE__)
+      typedef double d2 __attribute__((ext_vector_type(2)));
+      d2 v; v.x = x.v[i]; v.y = x.v[i + 1];
+#if RRTMG_SCR_NT
+      __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(q));
+#else
+      *reinterpret_cast<d2 *>(q) = v;
+#endif
+#else
+      q[0] = x.v[i]; q[1] = x.v[i + 1];
+#endif
+    }
+  } else {
+    _Pragma("unroll") for (int i = 0; i < G; ++i) p[i] = x.v[i];
+  }
+}
+
+// Partial-flux planes: written once by a solve kernel, read once by the flux kernel.  RRTMG_PART_NT: non-temporal accesses.
+#ifndef RRTMG_PART_NT
+#define RRTMG_PART_NT 1
+#endif
+RRTMG_HD void part_store(double *p, double v) {
+#if defined(__HIP_DEVICE_COMPILE__) && RRTMG_PART_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+RRTMG_HD double part_load(const double *p) {
+#if defined(__HIP_DEVICE_COMPILE__) && RRTMG_PART_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+
 // g-point-fastest table view: element (row, ig0 + j) at p[row * NG + j], p already offset by the first g-point
 template <int G, int NG> struct KTab {
   const double *p;

@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + lane * g;
+  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * g);
   LwPartSink sink = lw_part_sink(d, slot, col);
   lw_solve_item<CLD, MR, kLdsK>(d, T, item, col, scr, 64, sink, sh_k);
 }

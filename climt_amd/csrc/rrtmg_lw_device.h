@@ -907,17 +907,17 @@ struct LwPartSink {
   double *p;       // part + (slot*nk*(L+1))*N + col
   long N, st;      // st = (L+1)*N
   bool idrv;
-  RRTMG_HD void dn(int lev, double rd, double rcd) { p[st + (long)lev * N] = rd; p[3 * st + (long)lev * N] = rcd; }
+  RRTMG_HD void dn(int lev, double rd, double rcd) { part_store(p + st + (long)lev * N, rd); part_store(p + 3 * st + (long)lev * N, rcd); }
   RRTMG_HD void up(int lev, double ru, double rcu, double du, double dcu) {
-    p[(long)lev * N] = ru; p[2 * st + (long)lev * N] = rcu;
-    if (idrv) { p[4 * st + (long)lev * N] = du; p[5 * st + (long)lev * N] = dcu; }
+    part_store(p + (long)lev * N, ru); part_store(p + 2 * st + (long)lev * N, rcu);
+    if (idrv) { part_store(p + 4 * st + (long)lev * N, du); part_store(p + 5 * st + (long)lev * N, dcu); }
   }
   // cloud-free column (CLD = false variant): the clear-sky radiances ARE the total ones, so only the total planes
   // are written and lw_flux_level(cld = false) reads them for both outputs (half the partial-plane traffic)
-  RRTMG_HD void dn_clear(int lev, double rd) { p[st + (long)lev * N] = rd; }
+  RRTMG_HD void dn_clear(int lev, double rd) { part_store(p + st + (long)lev * N, rd); }
   RRTMG_HD void up_clear(int lev, double ru, double du) {
-    p[(long)lev * N] = ru;
-    if (idrv) p[4 * st + (long)lev * N] = du;
+    part_store(p + (long)lev * N, ru);
+    if (idrv) part_store(p + 4 * st + (long)lev * N, du);
   }
 };
 RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
@@ -1168,9 +1168,9 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       srd = srd + W(radld[g]); srcd = srcd + W(radclrd[g]);
       plfrac_bot[g] = plf;
     }
-    vstore<G>(SP(LF_ATRANS, l), v_atrans);
-    vstore<G>(SP(LF_BBUGAS, l), v_bbugas);
-    if (icldlyr) { vstore<G>(SP(LF_ATOT, l), v_atot); vstore<G>(SP(LF_BBUTOT, l), v_bbutot); }
+    scr_store<G>(SP(LF_ATRANS, l), stride, v_atrans);
+    scr_store<G>(SP(LF_BBUGAS, l), stride, v_bbugas);
+    if (icldlyr) { scr_store<G>(SP(LF_ATOT, l), stride, v_atot); scr_store<G>(SP(LF_BBUTOT, l), stride, v_bbutot); }
     if constexpr (CLD) sink.dn(lev - 1, srd, srcd); else sink.dn_clear(lev - 1, srd);
   }
 
@@ -1206,7 +1206,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     V<G> r_atrans[kU], r_bbugas[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u)
-      if (lev0 + u <= L) { r_atrans[u] = vload<G>(SP(LF_ATRANS, lev0 + u - 1)); r_bbugas[u] = vload<G>(SP(LF_BBUGAS, lev0 + u - 1)); }
+      if (lev0 + u <= L) { r_atrans[u] = scr_load<G>(SP(LF_ATRANS, lev0 + u - 1), stride); r_bbugas[u] = scr_load<G>(SP(LF_BBUGAS, lev0 + u - 1), stride); }
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int lev = lev0 + u;
@@ -1232,7 +1232,7 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         }
       }
       V<G> r_atot, r_bbutot;
-      if (icldlyr) { r_atot = vload<G>(SP(LF_ATOT, l)); r_bbutot = vload<G>(SP(LF_BBUTOT, l)); }
+      if (icldlyr) { r_atot = scr_load<G>(SP(LF_ATOT, l), stride); r_bbutot = scr_load<G>(SP(LF_BBUTOT, l), stride); }
       double mr_start = 0.0, mr_clr1 = 0.0, mr_cld1 = 0.0, mr_cmb1 = 0.0, mr_cmb2 = 0.0, mr_clr2 = 0.0, mr_cld2 = 0.0;
       if (MR && icldlyr) {
         mr_start = d.mr[lw_mr_off(L, col, lev) + MR_ISTCLD * 64];
@@ -1338,11 +1338,11 @@ RRTMG_HD void lw_flux_sums(const LwDev &d, int col, int lev, int nparts, bool cl
   double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0, t4 = 0.0, t5 = 0.0;
   for (int iw = 0; iw < nparts; ++iw) {
     const double *p = d.part + ((long)iw * nk * (L + 1) + lev) * d.pcols + (col - d.col0);
-    t0 = t0 + p[0]; t1 = t1 + p[st];
-    if (d.idrv) t4 = t4 + p[4 * st];
+    t0 = t0 + part_load(p); t1 = t1 + part_load(p + st);
+    if (d.idrv) t4 = t4 + part_load(p + 4 * st);
     if (cld) {
-      t2 = t2 + p[2 * st]; t3 = t3 + p[3 * st];
-      if (d.idrv) t5 = t5 + p[5 * st];
+      t2 = t2 + part_load(p + 2 * st); t3 = t3 + part_load(p + 3 * st);
+      if (d.idrv) t5 = t5 + part_load(p + 5 * st);
     }
   }
   if (!cld) { t2 = t0; t3 = t1; t5 = t4; }   // the clear-sky variant wrote the total planes only (LwPartSink::dn_clear)

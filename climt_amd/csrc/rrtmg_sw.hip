@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * item_g(item);
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? (threadIdx.x & 63) * 2 : (threadIdx.x & 63) * item_g(item));
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<CLD, kLdsK>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + lane * item_g(item);
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * item_g(item));
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + lane * item_g(item);
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * item_g(item));
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }

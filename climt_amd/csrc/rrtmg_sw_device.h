@@ -836,13 +836,13 @@ struct SwPartSink {
   long N, slot_stride;             // slot_stride = 4 * (nlay + 1) * ncol
   RRTMG_HD void emit(int pair, int lev, double fu, double fd, double cu, double cd) {
     const long o = pair * slot_stride + (long)lev * N;
-    pfu[o] = fu; pfd[o] = fd; pcu[o] = cu; pcd[o] = cd;
+    part_store(pfu + o, fu); part_store(pfd + o, fd); part_store(pcu + o, cu); part_store(pcd + o, cd);
   }
   // cloud-free column (CLD = false variant): clear-sky == total, only the total planes are written and
   // sw_flux_level(pairs = false) reads them for both outputs
   RRTMG_HD void emit_clear(int lev, double fu, double fd) {
     const long o = (long)lev * N;
-    pfu[o] = fu; pfd[o] = fd;
+    part_store(pfu + o, fu); part_store(pfd + o, fd);
   }
 };
 RRTMG_HD SwPartSink sw_part_sink(const SwDev &d, int slot, int col) {
@@ -1026,11 +1026,11 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
       V<G> v0, v1;
 #pragma unroll
       for (int g = 0; g < G; ++g) { v0[g] = rupc[g]; v1[g] = rupdc[g]; }
-      vstore<G>(SP(F_RUP, l), v0); vstore<G>(SP(F_RUPD, l), v1);
+      scr_store<G>(SP(F_RUP, l), stride, v0); scr_store<G>(SP(F_RUPD, l), stride, v1);
       if (CLD && c.any_cloudy) {
 #pragma unroll
         for (int g = 0; g < G; ++g) { v0[g] = rup[g]; v1[g] = rupd[g]; }
-        vstore<G>(SP(F_NCLR + F_RUP, l), v0); vstore<G>(SP(F_NCLR + F_RUPD, l), v1);
+        scr_store<G>(SP(F_NCLR + F_RUP, l), stride, v0); scr_store<G>(SP(F_NCLR + F_RUPD, l), stride, v1);
       }
     }
   }
@@ -1046,8 +1046,8 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
     // (fetching these rows a level ahead costs more in registers than the latency it hides: measured)
     V<G> c_rc, c_rdc, c_r, c_rd;
     if (lev > 0) {
-      c_rc = vload<G>(SP(F_RUP, lev - 1)); c_rdc = vload<G>(SP(F_RUPD, lev - 1));
-      if (CLD && c.any_cloudy) { c_r = vload<G>(SP(F_NCLR + F_RUP, lev - 1)); c_rd = vload<G>(SP(F_NCLR + F_RUPD, lev - 1)); }
+      c_rc = scr_load<G>(SP(F_RUP, lev - 1), stride); c_rdc = scr_load<G>(SP(F_RUPD, lev - 1), stride);
+      if (CLD && c.any_cloudy) { c_r = scr_load<G>(SP(F_NCLR + F_RUP, lev - 1), stride); c_rd = scr_load<G>(SP(F_NCLR + F_RUPD, lev - 1), stride); }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -1147,11 +1147,11 @@ RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, boo
   for (int c = 0; c < T.nitem[0]; ++c) {
     const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
     if (pairs && T.chunk_npair[c] == 2) {
-      fu = fu + (p[0] + p[slot]); fd = fd + (p[st] + p[slot + st]); cu = cu + (p[2 * st] + p[slot + 2 * st]); cd = cd + (p[3 * st] + p[slot + 3 * st]);
+      fu = fu + (part_load(p) + part_load(p + slot)); fd = fd + (part_load(p + st) + part_load(p + slot + st)); cu = cu + (part_load(p + 2 * st) + part_load(p + slot + 2 * st)); cd = cd + (part_load(p + 3 * st) + part_load(p + slot + 3 * st));
     } else if (pairs) {
-      fu = fu + p[0]; fd = fd + p[st]; cu = cu + p[2 * st]; cd = cd + p[3 * st];
+      fu = fu + part_load(p); fd = fd + part_load(p + st); cu = cu + part_load(p + 2 * st); cd = cd + part_load(p + 3 * st);
     } else {
-      fu = fu + p[0]; fd = fd + p[st];
+      fu = fu + part_load(p); fd = fd + part_load(p + st);
     }
   }
   if (!pairs) { cu = fu; cd = fd; }   // the clear-sky variant wrote the total planes only (SwPartSink::emit_clear)
