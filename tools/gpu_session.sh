@@ -7,8 +7,8 @@ export RRTMG_HIP_ALLOW_SYNTHETIC_LW=1
 R=$1; shift
 O=gpurun_out
 mkdir -p $O
-stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py $f > $2; }
-pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f _solve_ > $2; }
+stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py $f > $2; rm -rf $1; }   # (the raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f _solve_ > $2; rm -rf $1; }
 for sec in "$@"; do
   echo "=== section $sec ($(date +%T))"
   case $sec in
