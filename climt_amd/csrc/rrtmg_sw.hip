@@ -248,7 +248,8 @@ __global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_wave
 // -- chunks of 4 g-points, so the item-invariant work (layer state, species mixtures, weights, row indices) is paid once per
 // 4 g-points, not per pair -- at 2 waves/SIMD: 238 VGPRs, no spills; 8-wave workgroups, one per CU, sharing the
 // transmittance table and the chunk's slice in LDS.  Against the round-1 kernel (pairs, 170 VGPRs, 3 waves/SIMD, 12-wave
-// workgroups): 1.91 -> 1.73 ms at 8192 columns; the partial sums still leave per PAIR, so results are bit-identical.
+// workgroups): 1.91 -> 1.73 ms at 8192 columns.  The partial sums leave per chunk, the two pairs' sums added in the order the
+// flux kernel added the pair slots of the round-1 kernel: bit-identical, half the partial-plane traffic.
 constexpr int kC4Waves = 8;
 __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   const int ngrp = (ntile + kC4Waves - 1) / kC4Waves;
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
     if (!mine) return;
   }
   if (d.only_item >= 0 && k != d.only_item) return;
-  const int id = T.sched[0][k], item = T.item[0][id], slot = item_iw0(item) >> 1;
+  const int id = T.sched[0][k], item = T.item[0][id], slot = id;      // one slot per chunk (sw_flux_sums mode 2)
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
   sw_stage_slice(T, item, sh_k, 64 * kC4Waves);
   __shared__ double sh_exp[kExpTblN];
@@ -278,9 +279,10 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
 }
 #endif
 
+constexpr int kSwCldFluxMode = RRTMG_SWC_G4 ? 2 : 1;   // how the cloudy tiles' partial planes are laid out (sw_flux_sums)
 __global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T, int tile0) {
   const int tile = tile0 + blockIdx.x, col = tile * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[tile] != 0);
+  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[tile] != 0 ? kSwCldFluxMode : 0);
 }
 __global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -298,7 +300,7 @@ __global__ void __launch_bounds__(64 * (kFluxLev + 1)) sw_fluxheat_kernel(SwDev 
   const bool act = col < d.ncol && lev <= d.nlay;
   if (act) {
     double fu, fd, cu, cd;
-    sw_flux_sums(d, T, col, lev, d.tile_cld[tile] != 0, fu, fd, cu, cd);
+    sw_flux_sums(d, T, col, lev, d.tile_cld[tile] != 0 ? kSwCldFluxMode : 0, fu, fd, cu, cd);
     if (j < kFluxLev || lev == d.nlay) {
       const long o = (long)lev * d.ncol + col;
       d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;

@@ -1067,9 +1067,11 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
       const int h = g >> 1;
       sfu[h] = sfu[h] + zinc[g] * fu; sfd[h] = sfd[h] + zinc[g] * fd; scu[h] = scu[h] + zinc[g] * cu; scd[h] = scd[h] + zinc[g] * cd;
     }
-    if constexpr (CLD) {
-#pragma unroll
-      for (int h = 0; h < G / 2; ++h) sink.emit(h, lev, sfu[h], sfd[h], scu[h], scd[h]);   // one slot per pair
+    if constexpr (CLD && G == 4) {
+      // one slot per chunk: the two pairs' sums added here, as the flux kernel added the pair slots of the round-1 kernel
+      sink.emit(0, lev, sfu[0] + sfu[1], sfd[0] + sfd[1], scu[0] + scu[1], scd[0] + scd[1]);
+    } else if constexpr (CLD) {
+      sink.emit(0, lev, sfu[0], sfd[0], scu[0], scd[0]);
     } else if constexpr (G == 4) {
       sink.emit_clear(lev, sfu[0] + sfu[1], sfd[0] + sfd[1]);   // one slot per chunk
     } else {
@@ -1140,25 +1142,29 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // one thread per (column, interface level): g-point sum in reference order
 // pairs = false: the column's tile ran the clear-sky variant, slot c holds chunk c; true: the cloudy variant, one
 // slot per pair of g-points -- the chunk sums are formed here, so the summation order is the same.
-RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, bool pairs, double &fu, double &fd, double &cu, double &cd) {
+RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, int mode, double &fu, double &fd, double &cu, double &cd) {
+  // mode 0: cloud-free tile, one slot per chunk, total-sky planes only (SwPartSink::emit_clear);
+  //      1: one slot per PAIR of g-points, four planes (the pairs item set: host emulation, RRTMG_SWC_G4=0 kernel) -- the
+  //         pairs of a chunk are added first, so that the sums associate exactly as in modes 0 and 2;
+  //      2: cloudy tile of the chunk-of-4 kernel, one slot per chunk, four planes
   const int L = d.nlay, P = d.pcols;
   fu = 0.0; fd = 0.0; cu = 0.0; cd = 0.0;
   const long st = (long)(L + 1) * P, slot = 4 * st;
   for (int c = 0; c < T.nitem[0]; ++c) {
-    const double *p = d.part + (long)(pairs ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
-    if (pairs && T.chunk_npair[c] == 2) {
+    const double *p = d.part + (long)(mode == 1 ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
+    if (mode == 1 && T.chunk_npair[c] == 2) {
       fu = fu + (part_load(p) + part_load(p + slot)); fd = fd + (part_load(p + st) + part_load(p + slot + st)); cu = cu + (part_load(p + 2 * st) + part_load(p + slot + 2 * st)); cd = cd + (part_load(p + 3 * st) + part_load(p + slot + 3 * st));
-    } else if (pairs) {
+    } else if (mode != 0) {
       fu = fu + part_load(p); fd = fd + part_load(p + st); cu = cu + part_load(p + 2 * st); cd = cd + part_load(p + 3 * st);
     } else {
       fu = fu + part_load(p); fd = fd + part_load(p + st);
     }
   }
-  if (!pairs) { cu = fu; cd = fd; }   // the clear-sky variant wrote the total planes only (SwPartSink::emit_clear)
+  if (mode == 0) { cu = fu; cd = fd; }
 }
-RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool pairs) {
+RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, int mode) {
   double fu, fd, cu, cd;
-  sw_flux_sums(d, T, col, lev, pairs, fu, fd, cu, cd);
+  sw_flux_sums(d, T, col, lev, mode, fu, fd, cu, cd);
   const long o = (long)lev * d.ncol + col;
   d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
 }
