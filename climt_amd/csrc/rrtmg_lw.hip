@@ -1,15 +1,17 @@
 // rrtmg_lw.hip -- longwave kernels and launch sequence (gfx950).
 //
-// Launch sequence of one rrtmg_hip_lw_fluxes call (all on ctx->stream):
-//   lw_prep_layer_kernel <<<ncol/64, nlay>>>    inatm + setcoef per (column, layer)
-//   lw_prep_kernel       <<<ncol/64>>>          column part: laytrop, precipitable water -> secdiff
-//   lw_cloud_kernel      (icld>=1, non-McICA)   cldprop per column (layer-order dependent ncbands)
+// Launch sequence of one rrtmg_hip_lw_fluxes call (all on the context's longwave stream):
+//   lw_prep_fused_kernel <<<tiles, 16 waves>>>  inatm + setcoef per (column, layer), then the column part (laytrop, precipitable
+//                        water -> secdiff, tile cloud flag) on what the layer part left in LDS; non-McICA cloudy tiles: cldprop
+//                        and the rtrnmr overlap factors         (RRTMG_HIP_UNFUSED=1: lw_prep_layer_kernel, lw_prep_kernel,
+//                        lw_cloud_kernel, lw_mr_kernel as separate launches)
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
-//   lw_solve_all_kernel  one launch per variant (clear / cloudy tiles): wavefront = tile(64 columns) x work item (4|2 g-points
-//                        of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
-//   lw_flux_kernel       <<<ncol/64, nlay+1>>>  band / g-point integration per interface
-//   lw_heat_kernel       <<<ncol/64, nlay>>>    heating rates
+//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles):
+//     lw_solve_all_kernel  one launch per variant (cloud-free / cloudy tiles): wavefront = tile(64 columns) x work item (4|2
+//                          g-points of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
+//     lw_fluxheat_kernel   <<<(tiles, levels/15), 16 waves>>>  band / g-point integration per interface + heating rates
+//                          (RRTMG_HIP_UNFUSED=2: lw_flux_kernel + lw_heat_kernel)
 #include "rrtmg_ctx.h"
 #include "rrtmg_lw_device.h"
 #include "rrtmg_lw_host.h"

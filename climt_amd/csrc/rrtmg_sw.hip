@@ -1,15 +1,17 @@
 // rrtmg_sw.hip -- shortwave kernels and launch sequence (gfx950).
 //
-// Launch sequence of one rrtmg_hip_sw_fluxes call (all on ctx->stream):
-//   sw_prep_layer_kernel <<<ncol/64, nlay>>>     inatm_sw + setcoef_sw per (column, layer)
-//   sw_prep_kernel      <<<ncol/64, 14>>>        column part: laytrop, cloud flag; solar-source layer per band
+// Launch sequence of one rrtmg_hip_sw_fluxes call (all on the context's shortwave stream):
+//   sw_prep_fused_kernel <<<tiles, 16 waves>>>   inatm_sw + setcoef_sw per (column, layer), then the column part from the index
+//                        words in LDS (laytrop, cloud flag, solar-source layer per band); non-McICA cloudy tiles: the band cloud
+//                        optics           (RRTMG_HIP_UNFUSED=1: sw_prep_layer_kernel, sw_prep_kernel, sw_cloud_kernel)
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
-//   sw_cloud_kernel     (icld >= 1)              band cloud optics per (column, layer)
-//   kiss_mask_kernel / mask upload (mcica)       sub-column cloud mask
-//   sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel: wavefront = tile(64 columns) x work item
-//                       (4|2 g-points of a band), workgroup = 16 | 4 tiles of one item sharing its tables in LDS
-//   sw_flux_kernel      <<<ncol/64, nlay+1>>>    g-point sum per interface
-//   sw_heat_kernel      <<<ncol/64, nlay>>>      heating rates
+//   sw_cloud_kernel     (McICA)                  band cloud optics per (column, layer)
+//   kiss_mask_kernel / mask upload (McICA)       sub-column cloud mask
+//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles):
+//     sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel (cloudy tiles): wavefront = tile(64 columns) x work
+//                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS
+//     sw_fluxheat_kernel  <<<(tiles, levels/15), 16 waves>>>  g-point sum per interface + heating rates
+//                         (RRTMG_HIP_UNFUSED=2: sw_flux_kernel + sw_heat_kernel)
 #include "rrtmg_ctx.h"
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
