@@ -167,6 +167,7 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the McICA / end-to-end extras (N=1)")
     ap.add_argument("--lw-first", action="store_true", help="enqueue the longwave before the shortwave (N=1; experiment)")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
+    ap.add_argument("--sync-every-step", action="store_true", help="host synchronize after every step inside the timed brackets too (N=1)")
     ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default) or torch.distributed")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (2 ranks on a 1-GPU box; with --dist-backend gloo)")
@@ -237,9 +238,9 @@ def main():
             (so if i < 6 else lo)[k] = flat.ptr + 8 * off
             off += s
         ctx.set_deferred(not serial)
-        enq = [0.0, 0.0]
+        enq = [0.0, 0.0, 0]
 
-        def step():
+        def enqueue():
             t = time.perf_counter()
             if a.lw_first:
                 ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
@@ -248,24 +249,45 @@ def main():
             if not a.lw_first:
                 ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
             enq[1] += time.perf_counter() - t
+            enq[2] += 1
+
+        def step():
+            enqueue()
             ctx.synchronize()
         for _ in range(warmup):
             step()
         _hip.synchronize()
         enq[0] = enq[1] = 0.0
-        per, ksw, klw, brackets = [], [], [], []
+        enq[2] = 0
+        per, ksw, klw, brackets, synced = [], [], [], [], []
         for _ in range(reps_of(steps, ncol, nlay, cld)):      # EXACTLY `steps` steps per bracket; brackets repeated to >= 1 s
             _hip.synchronize()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                t = time.perf_counter()
-                step()
-                per.append((time.perf_counter() - t) * 1e3)
-                ksw.append(ctx.kernel_ms("sw", cloudy=cld))
-                klw.append(ctx.kernel_ms("lw", cloudy=cld))
+            if serial or a.sync_every_step:
+                for _ in range(steps):
+                    step()
+            else:
+                # the host does not wait between steps (nor would a model whose state is resident on the device): each
+                # stream orders step i + 1 behind step i, the status flags are sticky, one synchronize closes the bracket
+                for _ in range(steps):
+                    enqueue()
+                ctx.synchronize()
             _hip.synchronize()
             brackets.append((time.perf_counter() - t0) * 1e3 / steps)
         ms = float(np.median(brackets))
+        # per-step latency, host enqueue time and the event-timed kernel durations: a bracket with a host synchronize after
+        # every step (an enqueue behind a full queue would measure the GPU, not the host)
+        _hip.synchronize()
+        enq[0] = enq[1] = 0.0
+        enq[2] = 0
+        t0 = time.perf_counter()
+        for _ in range(min(steps, 200)):
+            t = time.perf_counter()
+            step()
+            per.append((time.perf_counter() - t) * 1e3)
+            ksw.append(ctx.kernel_ms("sw", cloudy=cld))
+            klw.append(ctx.kernel_ms("lw", cloudy=cld))
+        synced.append((time.perf_counter() - t0) * 1e3 / max(1, len(per)))
         ctx.set_deferred(False)
         ssw, slw = [], []
         for _ in range(3):      # kernel durations without the SW||LW overlap, for reference
@@ -273,17 +295,17 @@ def main():
             ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
             ssw.append(ctx.kernel_ms("sw", cloudy=cld))
             slw.append(ctx.kernel_ms("lw", cloudy=cld))
-        n_all = max(1, len(per))
-        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets)
+        n_all = max(1, enq[2])
+        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0])
 
     def reps_of(k, ncol, nlay, cld):
         """Brackets of exactly k steps needed for >= 1 s of timed region (1 when k was chosen by pick_steps)."""
-        est = ncol * (nlay / 60.0) / (2.0e6 if cld else 4.0e6)
+        est = ncol * (nlay / 60.0) / (2.7e6 if cld else 5.4e6)
         return int(max(1, min(400, np.ceil(1.2 / (k * est)))))
 
     def pick_steps(ncol, nlay, cld):
         """Enough steps for >= 1 s of timed region (estimated from the large-grid rates of DESIGN.md 5)."""
-        est = ncol * (nlay / 60.0) / (2.0e6 if cld else 4.0e6)
+        est = ncol * (nlay / 60.0) / (2.7e6 if cld else 5.4e6)
         return max(10, int(np.ceil(1.2 / est)))
 
     steps = a.steps if a.steps is not None else pick_steps(N, L, cloudy)
@@ -339,20 +361,20 @@ def main():
         if a.serial:
             ctx.set_deferred(False)
         sr.set_inputs(columns(N, L, cloudy), already_local=True)
-        host_wait = comm.kind != "rccl"
+        host_wait = comm.kind != "rccl" and sr.do_gather      # (nothing to wait for before a gather that does not run)
 
         gather_error = []
 
-        def step():
+        def step(sync=True):
             try:
-                return sr.step(mcica=cloudy, host_wait=host_wait)
+                return sr.step(mcica=cloudy, host_wait=host_wait, sync=sync or host_wait)
             except Exception as e:      # keep measuring the compute; the JSON line says that the gather did not run
                 if not sr.do_gather:
                     raise
                 gather_error.append("%s: %s" % (type(e).__name__, str(e)[:200]))
                 sr.do_gather = False
                 sr.inflight = [False] * sr.nbuf
-                return sr.step(mcica=cloudy, host_wait=host_wait)
+                return sr.step(mcica=cloudy, host_wait=host_wait, sync=sync or host_wait)
 
         def fence():
             sr.finish()
@@ -365,17 +387,21 @@ def main():
         for _ in range(reps_of(steps, N, L, cloudy)):      # EXACTLY `steps` steps per bracket (barrier + sync on both sides)
             fence()
             t0 = time.perf_counter()
-            for _ in range(steps):
-                t = time.perf_counter()
-                step()
-                per.append((time.perf_counter() - t) * 1e3)
-                ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
-                klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
+            for _ in range(steps):      # as at N=1: no host synchronize between the steps of a bracket (unless asked for)
+                step(sync=a.serial or a.sync_every_step)
             fence()
             t = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], dtype=torch.float64, device="cuda:%d" % local)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's bracket
             brackets.append(float(t.item()))
         ms = float(np.median(brackets))
+        fence()
+        for _ in range(min(steps, 200)):      # per-step latency and kernel durations: synchronized steps, outside the brackets
+            t = time.perf_counter()
+            step()
+            per.append((time.perf_counter() - t) * 1e3)
+            ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
+            klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
+        fence()
         r = dict(ksw=ksw, klw=klw, ssw=ksw, slw=klw, enq_sw=0.0, enq=0.0, brackets=brackets)
         if gather_error:
             comm_note += "output gather FAILED and was switched off (%s); " % gather_error[0]
@@ -409,6 +435,8 @@ def main():
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
                        "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
                        "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
+                       "host_sync": ("after every step" if (a.serial or a.sync_every_step) else
+                                     "one per bracket: the host enqueues the K steps back to back (each stream orders step i+1 behind step i) and synchronizes once; ms_per_step_median / p10_p90 below come from a separate bracket with a synchronize after every step"),
                        "ms_per_step_median": float(np.median(per)),
                        "ms_per_step_p10_p90": [float(np.percentile(per, 10)), float(np.percentile(per, 90))],
                        "lw_k_tables": "synthetic (reference LW data file missing)", "sw_k_tables": "reference"},

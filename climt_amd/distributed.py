@@ -296,10 +296,13 @@ class ShardedRadiation:
         lw = {k: o[k] for k in self.names[len(SW_OUT):]}
         return sw, lw
 
-    def step(self, mcica=False, host_wait=False):
+    def step(self, mcica=False, host_wait=False, sync=True):
         """One LW+SW pass over this rank's block into buffer b = step number mod nbuf; starts its gather; returns b.
         host_wait: the communicator cannot be ordered after the kernels on the device (no stream of its own): the host
-        waits for the kernels before it starts the gather."""
+        waits for the kernels before it starts the gather.
+        sync=False: do not wait for this step's kernels (a time loop that needs nothing on the host: the streams order
+        step i+1 behind step i, the status flags are sticky and are collected by the next synchronizing step or finish();
+        the host still waits for the gather that last read the buffer this step writes, nbuf steps back)."""
         b = self.i % self.nbuf
         self.i += 1
         if self.inflight[b]:                      # the gather that read this buffer (nbuf steps ago) must be done
@@ -327,12 +330,14 @@ class ShardedRadiation:
                 self.events[b].record(self.comm.stream.s)
             self.inflight[b] = True
             self._host_wait = host_wait
-        if self.device:
+        if self.device and sync:
             self.ctx.synchronize()                # this step's kernels are complete and their status checked
         return b
 
     def finish(self):
-        """Wait for every gather in flight."""
+        """Wait for every gather in flight and for the kernels (their status is checked)."""
+        if self.device:
+            self.ctx.synchronize()
         for b in range(self.nbuf):
             if self.inflight[b]:
                 if self.device and not getattr(self, "_host_wait", False):

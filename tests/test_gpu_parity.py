@@ -798,8 +798,8 @@ def test_3d_reference_caches_from_generated_default_state(cls):
 @pytest.mark.parametrize("mode", ["all", "root", "none"])
 def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
     """climt_amd.distributed.ShardedRadiation on the device with RcclComm (librccl bound through ctypes, its own stream,
-    device-side ordering after the kernels): one rank, collective forced, three steps so that both halves of the double
-    buffer are gathered -- against the plain device call.  (Multi-rank logic: world-size-2 gloo test on CPU.)"""
+    device-side ordering after the kernels): one rank, collective forced, four steps so that both halves of the double
+    buffer are gathered and re-used -- against the plain device call.  (Multi-rank logic: world-size-2 gloo test on CPU.)"""
     from climt_amd.distributed import RcclComm, ShardedRadiation
     from climt_amd.synthetic import make_columns
     N, L = 1000, 40
@@ -809,8 +809,8 @@ def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
     try:
         sr = ShardedRadiation(gpu_ctx, comm, N, L, gather=mode, force=True)
         sr.set_inputs(c)
-        for _ in range(3):
-            b = sr.step(mcica=True)
+        for i in range(4):
+            b = sr.step(mcica=True, sync=(i == 1))      # steps without a host synchronize too (a time loop on the device)
         sr.finish()
         got = sr.gathered_host(b)
         assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
