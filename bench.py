@@ -502,6 +502,43 @@ def main():
                                                               "sympl-style DataArrays in, tendencies + diagnostics out" % (N // 128, L)}
                 except Exception as e:   # pragma: no cover
                     extra["end_to_end_components"] = {"error": repr(e)[:200]}
+                # (d) SURVEY 8(f)3: the whole model step either side of the path with the state resident on the device --
+                # Instellation -> RRTMG SW + LW (every step) -> Adams-Bashforth -> SlabSurface on a DeviceState, through the
+                # same component classes; the host does not wait between steps
+                try:
+                    import datetime as dtm
+                    import climt_amd
+                    kw = dict(mcica=True, random_number_generator="kissvec") if cloudy else {}
+                    sun, slab = climt_amd.Instellation(), climt_amd.SlabSurface()
+                    lw_d, sw_d = climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **kw), climt_amd.RRTMGShortwave(**kw)
+                    host_state = climt_amd.get_default_state([sun, lw_d, sw_d, slab], grid_state=climt_amd.get_grid(nx=128, ny=N // 128, nz=L))
+                    ds = climt_amd.DeviceState.from_host(host_state, [sun, lw_d, sw_d, slab])
+                    stepper = climt_amd.DeviceAdamsBashforth(lw_d, sw_d, slab, wait_every_step=False)
+                    dt_model = dtm.timedelta(seconds=600)
+
+                    def model_step():
+                        nonlocal ds
+                        ds.update(sun(ds))
+                        diag, ds = stepper(ds, dt_model)
+                        ds.update(diag)
+                        ds["time"] = ds["time"] + dt_model
+                    for _ in range(3):
+                        model_step()
+                    _hip.synchronize()
+                    n_m = 300
+                    t0 = time.perf_counter()
+                    for _ in range(n_m):
+                        model_step()
+                    ds.ctx.synchronize()
+                    _hip.synchronize()
+                    mstep = (time.perf_counter() - t0) / n_m
+                    extra["device_resident_model_step"] = {
+                        "value": 128 * (N // 128) / mstep, "unit": "columns/s", "ms_per_step": mstep * 1e3, "steps": n_m,
+                        "note": "Instellation -> RRTMGShortwave + RRTMGLongwave (refreshed every step) -> DeviceAdamsBashforth -> SlabSurface on "
+                                "climt_amd.DeviceState(get_default_state(128 x %d x %d)): the state stays in HBM, tendency sums and the time "
+                                "step are kernels, nothing returns to the host (the default state has no clouds)" % (N // 128, L)}
+                except Exception as e:   # pragma: no cover
+                    extra["device_resident_model_step"] = {"error": repr(e)[:200]}
                 res["extra"] = extra
             if not a.no_cpu_baseline:
                 res["cpu_baseline"] = cpu_baseline(L, cloudy)

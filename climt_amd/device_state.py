@@ -349,9 +349,13 @@ def _rate(units):
 class DeviceAdamsBashforth:
     """sympl's AdamsBashforth around TendencyComponents (tests/test_components.py:123-160), on a DeviceState: tendencies of
     all components summed in "<state units> per second", order ramping 1 -> 2 -> 3, prognostic quantities replaced in the
-    state -- every sum and the update are kernels on the context's main stream.  Returns (diagnostics, the same state)."""
+    state -- every sum and the update are kernels on the context's main stream.  Returns (diagnostics, the same state).
+    wait_every_step=False: the host does not wait for the step (a time loop that reads nothing back keeps the GPU busy while
+    the host prepares the next step); the device-side `stop` conditions are sticky and surface at the next download(),
+    Context.synchronize() or waiting step."""
 
-    def __init__(self, *components, order=3):
+    def __init__(self, *components, order=3, wait_every_step=True):
+        self._wait = bool(wait_every_step)
         if len(components) == 1 and isinstance(components[0], (list, tuple)):
             components = tuple(components[0])
         if order not in _AB:
@@ -391,5 +395,6 @@ class DeviceAdamsBashforth:
             ctx.ab_step(old.size, old.ptr, hist, weights[: len(hist)], dt, new.ptr)
             ds[name] = new
         ds.step_count += 1
-        ctx.synchronize()          # device-side `stop` conditions of this step surface here
+        if self._wait:
+            ctx.synchronize()      # device-side `stop` conditions of this step surface here
         return diagnostics, ds
