@@ -165,6 +165,15 @@ class DeviceState(dict):
         (self.ctx.sw_init if which == "sw" else self.ctx.lw_init)(cpd)      # (idempotent per context)
 
     # ---- back to the host ----------------------------------------------------------------------------------------
+    def join_streams(self):
+        """Main-stream work enqueued from here on runs after the longwave that is in flight on its own stream.  Called by
+        whatever consumes the longwave's outputs or overwrites its inputs on the main stream -- NOT by the shortwave call, so a
+        stepper that calls the longwave and then the shortwave gets the two side by side (ordering the main stream behind the
+        longwave inside the longwave call, as this did at first, ran them back to back: 1.87 instead of 1.6 ms per step)."""
+        if getattr(self, "_lw_inflight", False):
+            self.ctx.order_streams(1)
+            self._lw_inflight = False
+
     def download(self, name, synchronize=True):
         """The quantity as a host DataArray: wildcard re-expanded to the horizontal dims it was uploaded with."""
         if synchronize:
@@ -193,6 +202,7 @@ def _derived(ds, comp_inputs):
     if ds._derived_ok:
         return ds._work["derived_vals"]
     ctx = ds.ctx
+    ds.join_streams()      # a longwave still in flight reads the buffers rewritten here
     t, p, pi = ds["air_temperature"], ds["air_pressure"], ds["air_pressure_on_interface_levels"]
     nlay, ncol = t.shape
     out = {}
@@ -294,7 +304,7 @@ def longwave_device_call(self, ds):
         out.update(duflx_dt=du.ptr, duflxc_dt=duc.ptr)
         self.change_in_upward_flux_with_surface_temperature, self.change_in_clear_sky_upward_flux_with_surface_temperature = du, duc
     ds.ctx.lw_fluxes(inp, mcica=self._mcica, out=out, memspace=1)
-    ds.ctx.order_streams(1)          # consumers (tendency sum, slab) run on the main stream, after the longwave
+    ds._lw_inflight = True      # consumers on the main stream (tendency sum, slab, the next derived fields) join first: join_streams()
     diagnostics = {
         "upwelling_longwave_flux_in_air": fl["uflx"], "downwelling_longwave_flux_in_air": fl["dflx"],
         "upwelling_longwave_flux_in_air_assuming_clear_sky": fl["uflxc"], "downwelling_longwave_flux_in_air_assuming_clear_sky": fl["dflxc"],
@@ -320,6 +330,7 @@ def slab_device_call(self, ds):
                  sea_water_dens="sea_water_density", surf_dens="surface_material_density", heat_cap_soil="heat_capacity_of_soil",
                  surf_therm_cap="surface_thermal_capacity", ocean_mix_thick="ocean_mixed_layer_thickness", soil_layer_thick="soil_layer_thickness",
                  ocean_heat_transport="ocean_heat_transport_convergence")
+    ds.join_streams()      # the longwave fluxes in the state may be this step's
     ptrs = {}
     for k in SLAB_IN:
         q = ds[names[k]]
@@ -372,12 +383,18 @@ class DeviceAdamsBashforth:
             raise ValueError("timestep must be constant for Adams-Bashforth time stepping")
         ctx, total, diagnostics = ds.ctx, {}, {}
         slot = self._slot = (self._slot + 1) % (self._order + 1)
+        # every component first (the longwave goes to its own stream: the shortwave enqueued behind it on the main stream runs
+        # beside it), then the sums in component order
+        results = []
         for comp in self.component_list:
             tend, diag = comp(ds)
             overlap = set(diag) & set(diagnostics)
             if overlap:
                 raise ValueError("two components compute the same diagnostics: %s" % sorted(overlap))
             diagnostics.update(diag)
+            results.append(tend)
+        ds.join_streams()
+        for tend in results:
             for name, q in tend.items():
                 acc = ds.work(("ab", id(self), name, slot), q.shape, q.dims, ds[name].units + " s^-1")
                 if name in total:
