@@ -13,9 +13,9 @@ import os
 
 import numpy as np
 
-from .._sympl_compat import TendencyComponent, get_constant, initialize_numpy_arrays_with_properties
+from .._sympl_compat import TendencyComponent, get_constant
 from .._util import ensure_contiguous_state, get_interface_values, mass_to_volume_mixing_ratio
-from .common import (make_context, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict, rrtmg_cloud_overlap_method_dict,
+from .common import (OutputPool, make_context, output_arrays, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict, rrtmg_cloud_overlap_method_dict,
                      rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
 
@@ -102,6 +102,7 @@ class RRTMGLongwave(TendencyComponent):
         if not self._calc_Tint:
             self.input_properties["air_temperature_on_interface_levels"] = _prop(_IL, "degK")
         self._ctx = make_context(device)
+        self._pool = OutputPool()
         self._ctx.lw_init(self._Cpd)
         if self._ctx.lw_tables_synthetic():
             msg = ("RRTMGLongwave: the longwave k-distribution tables in this build are SYNTHETIC (the reference data "
@@ -132,8 +133,9 @@ class RRTMGLongwave(TendencyComponent):
         # calculate_interface_temperature: the log-pressure interpolation (lw/component.py:378-384) is done by the library on
         # the device (tlev = None), not by numpy here -- 4 ms of np.log per call at 128 x 64 x 60
         T_interface = None if self._calc_Tint else state["air_temperature_on_interface_levels"]
-        diagnostics = initialize_numpy_arrays_with_properties(self.diagnostic_properties, state, self.input_properties)
-        tendencies = initialize_numpy_arrays_with_properties(self.tendency_properties, state, self.input_properties)
+        # (recycled when the caller has dropped an earlier call's results: the library overwrites every element)
+        diagnostics = output_arrays(self._pool, self.diagnostic_properties, state, self.input_properties)
+        tendencies = output_arrays(self._pool, self.tendency_properties, state, self.input_properties)
         inp = dict(
             play=state["air_pressure"], plev=state["air_pressure_on_interface_levels"], tlay=state["air_temperature"],
             tlev=T_interface, tsfc=state["surface_temperature"], h2o=Q, o3=state["mole_fraction_of_ozone_in_air"],

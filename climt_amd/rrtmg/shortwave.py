@@ -6,9 +6,9 @@ import logging
 
 import numpy as np
 
-from .._sympl_compat import TendencyComponent, get_constant, initialize_numpy_arrays_with_properties
+from .._sympl_compat import TendencyComponent, get_constant
 from .._util import ensure_contiguous_state, get_interface_values, mass_to_volume_mixing_ratio
-from .common import (make_context, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
+from .common import (OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
                      rrtmg_cloud_overlap_method_dict, rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
 
@@ -118,6 +118,7 @@ class RRTMGShortwave(TendencyComponent):
         self._solar_const = 0 if use_solar_constant_from_fortran else get_constant("stellar_irradiance", "W/m^2")
         self._Cpd = get_constant("heat_capacity_of_dry_air_at_constant_pressure", "J/kg/K")
         self._ctx = make_context(device)
+        self._pool = OutputPool()
         # the reference re-runs rrtmg_sw_ini on every McICA call (sw/component.py:547-560); the tables do
         # not depend on the call, so they are built once here
         self._ctx.sw_init(self._Cpd)
@@ -138,8 +139,9 @@ class RRTMGShortwave(TendencyComponent):
         assert state["air_pressure"].shape[0] + 1 == state["air_pressure_on_interface_levels"].shape[0]
         # (the reference also interpolates interface temperatures here, sw/component.py:492-496; RRTMG_SW never reads them)
         Tint = None
-        diagnostics = initialize_numpy_arrays_with_properties(self.diagnostic_properties, state, self.input_properties)
-        tendencies = initialize_numpy_arrays_with_properties(self.tendency_properties, state, self.input_properties)
+        # (recycled when the caller has dropped an earlier call's results: the library overwrites every element)
+        diagnostics = output_arrays(self._pool, self.diagnostic_properties, state, self.input_properties)
+        tendencies = output_arrays(self._pool, self.tendency_properties, state, self.input_properties)
         day_of_year = 0 if self._ignore_day_of_year else state["time"].timetuple().tm_yday
         inp = dict(
             play=state["air_pressure"], plev=state["air_pressure_on_interface_levels"], tlay=state["air_temperature"], tlev=Tint,

@@ -249,3 +249,28 @@ def check_3d_cache_from_generated_state(cls):
 @pytest.mark.parametrize("cls", ["TestRRTMGShortwave", "TestRRTMGLongwave"])
 def test_3d_caches_from_generated_default_state(cls):
     check_3d_cache_from_generated_state(cls)
+
+
+def test_output_pool_never_hands_out_an_array_somebody_still_holds():
+    """climt_amd.rrtmg.common.OutputPool: the radiation components write into the arrays of an EARLIER call only when the
+    caller has dropped every reference to them (DataArray, raw array, any view) -- the reference allocates afresh each call,
+    and a recycled array must be indistinguishable from that."""
+    from climt_amd.rrtmg.common import OutputPool, output_arrays
+    pool = OutputPool()
+    a = pool.zeros_like_fresh("x", (3, 4))
+    b = pool.zeros_like_fresh("x", (3, 4))
+    assert a is not b and not a.any()                      # `a` is held: a new array
+    ida = id(a)
+    view = a[1]                                            # a view keeps its base alive through .base
+    del a
+    c = pool.zeros_like_fresh("x", (3, 4))
+    assert id(c) != ida and c is not b
+    del view
+    d = pool.zeros_like_fresh("x", (3, 4))
+    assert id(d) == ida                                    # nobody holds it any more: handed out again
+    assert pool.zeros_like_fresh("x", (4, 3)).shape == (4, 3) and pool.zeros_like_fresh("y", (3, 4)) is not d
+    # shapes as initialize_numpy_arrays_with_properties derives them
+    props_in = {"t": {"dims": ["mid_levels", "*"], "units": "K"}, "p": {"dims": ["interface_levels", "*"], "units": "Pa"}}
+    raw = {"t": np.zeros((5, 7)), "p": np.zeros((6, 7))}
+    out = output_arrays(pool, {"f": {"dims": ["interface_levels", "*"], "units": "W m^-2"}, "t": {"units": "K s^-1"}}, raw, props_in)
+    assert out["f"].shape == (6, 7) and out["t"].shape == (5, 7)

@@ -460,6 +460,29 @@ def test_components_on_gpu_reproduce_reference_caches():
             raise RuntimeError("SYNTHETIC (real tables: nothing to refuse)")
 
 
+def test_component_outputs_are_recycled_only_when_dropped():
+    """The drop-in components reuse the output arrays of an earlier call only when the caller holds nothing of it any more
+    (climt_amd.rrtmg.common.OutputPool): results that are kept stay intact, as with the reference's fresh arrays."""
+    import climt_amd
+    sw, lw = climt_amd.RRTMGShortwave(), climt_amd.RRTMGLongwave(allow_synthetic_tables=True)
+    state = climt_amd.get_default_state([sw, lw], grid_state=climt_amd.get_grid(nx=16, ny=8, nz=20))
+    for comp, name in ((sw, "upwelling_shortwave_flux_in_air"), (lw, "upwelling_longwave_flux_in_air")):
+        t1, d1 = comp(state)
+        kept = {k: v.values.copy() for k, v in d1.items()}
+        state2 = dict(state)
+        ta = state["air_temperature"]
+        state2["air_temperature"] = type(ta)(ta.values + 5.0, dims=ta.dims, attrs=ta.attrs)      # different inputs: different results
+        t2, d2 = comp(state2)
+        assert all(np.array_equal(d1[k].values, kept[k]) for k in kept)           # the first call's arrays were not touched
+        assert not np.shares_memory(d1[name].values, d2[name].values)
+        addr = d1[name].values.__array_interface__["data"][0]
+        del t1, d1
+        t3, d3 = comp(state)                                                        # the first call's arrays are free now
+        assert d3[name].values.__array_interface__["data"][0] == addr
+        assert all(np.array_equal(d3[k].values, kept[k]) for k in kept)           # ... and hold the same results again
+        assert maxdiff(d2[name].values, d3[name].values) > 0.0
+
+
 def test_model_script_setup_from_scratch_steps_to_reference_stepping_caches():
     """state from get_grid/get_default_state (no fixture state), stepped 10 s by AdamsBashforth around
     the drop-in components, against the reference's `*_stepping` caches (tests/test_components.py:123-160)."""
