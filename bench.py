@@ -445,6 +445,11 @@ def main():
                          "algorithmic_bytes_per_column": bpc, "sw_solve_ms": sw_ms, "lw_solve_ms": lw_ms,
                          "sw_solve_ms_serial": float(np.mean(r["ssw"])), "lw_solve_ms_serial": float(np.mean(r["slw"])),
                          "kernel_ms_serial": kms_serial, "frac_serial": bpc * N / (kms_serial * 1e-3) / HBM_PEAK,
+                         # the whole LW+SW step: its algorithmic bytes ((34L+11)*8 SW + (56L+22)*8 LW per column)
+                         # over the step time -- the two solve kernels share the GPU in the timed region, so the duration of
+                         # either one alone there says how the scheduler split the CUs, not how fast the path is
+                         "step_algorithmic_bytes_per_column": (34 * L + 11) * 8 + (56 * L + 22) * 8,
+                         "step_frac": ((34 * L + 11) * 8 + (56 * L + 22) * 8) * N / (ms * 1e-3) / HBM_PEAK,
                          "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
                          "fp64_frac_serial": (flops / (kms_serial * 1e-3) / FP64_PEAK) if flops else None,
                          "host_call_ms": {"sw": r["enq_sw"], "sw+lw": r["enq"]},
