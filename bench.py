@@ -310,7 +310,7 @@ def main():
 
     steps = a.steps if a.steps is not None else pick_steps(N, L, cloudy)
     warmup = a.warmup if a.warmup is not None else max(2, min(10, steps // 20))
-    comm_note, comm_kind = "", None
+    comm_note, comm_kind, host_wait = "", None, False
 
     if not multi:
         r = device_run(N, L, cloudy, steps, warmup, a.serial)
@@ -435,7 +435,7 @@ def main():
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
                        "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
                        "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
-                       "host_sync": ("after every step" if (a.serial or a.sync_every_step) else
+                       "host_sync": ("after every step" if (a.serial or a.sync_every_step or (multi and host_wait)) else
                                      "one per bracket: the host enqueues the K steps back to back (each stream orders step i+1 behind step i) and synchronizes once; ms_per_step_median / p10_p90 below come from a separate bracket with a synchronize after every step"),
                        "ms_per_step_median": float(np.median(per)),
                        "ms_per_step_p10_p90": [float(np.percentile(per, 10)), float(np.percentile(per, 90))],
