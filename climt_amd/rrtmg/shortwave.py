@@ -7,7 +7,7 @@ import logging
 import numpy as np
 
 from .._sympl_compat import TendencyComponent, get_constant
-from .._util import ensure_contiguous_state, get_interface_values, mass_to_volume_mixing_ratio
+from .._util import ensure_contiguous_state, mass_to_volume_mixing_ratio
 from .common import (OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
                      rrtmg_cloud_overlap_method_dict, rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
