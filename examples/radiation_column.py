@@ -44,7 +44,8 @@ def main():
     dt = timedelta(seconds=a.dt)
     if a.device_resident:
         state = climt_amd.DeviceState.from_host(state, [sun, lw, sw, slab])
-        stepper = climt_amd.DeviceAdamsBashforth(lw, sw, slab)
+        # (the host need not wait for a step: the diagnostics printed below are downloaded, which synchronizes)
+        stepper = climt_amd.DeviceAdamsBashforth(lw, sw, slab, wait_every_step=False)
         host = lambda name: state.download(name).values
     else:
         stepper = climt_amd.AdamsBashforth(lw, sw, slab)
