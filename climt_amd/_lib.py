@@ -5,7 +5,9 @@ There is no CPU fallback: importing works anywhere (so property dictionaries can
 but creating a Context without the built library or without a GPU raises.
 """
 import ctypes as C
+import functools
 import os
+import threading
 
 import numpy as np
 
@@ -88,6 +90,8 @@ def load_library():
     lib.rrtmg_hip_slab_surface.argtypes = [_vp, C.c_int, C.c_int, C.POINTER(SlabArgs)]
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
+    lib.rrtmg_hip_kernel_launches.argtypes = [_vp, C.c_int]
+    lib.rrtmg_hip_copy_blocks.argtypes = [_vp, C.c_int, _vp, C.c_long, C.c_long, _vp, _vp, _vp]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
     return lib
@@ -114,11 +118,25 @@ SW_OUT = (("swuflx", 1), ("swdflx", 1), ("swhr", 0), ("swuflxc", 1), ("swdflxc",
 LW_OUT = (("uflx", 1), ("dflx", 1), ("hr", 0), ("uflxc", 1), ("dflxc", 1), ("hrc", 0))
 
 
+def _locked(fn):
+    """Context methods that enter the library hold the context's lock: ctypes releases the GIL for the duration of a
+    call, and a context -- its staging buffers, work-buffer map, error string, streams -- is shared by every component of
+    the process on that device (climt_amd.rrtmg.common.make_context), so two Python threads must not be inside it at once."""
+    @functools.wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        with self._lock:
+            return fn(self, *args, **kwargs)
+    return wrapper
+
+
 class Context:
-    """One librrtmg_hip context: constants, device tables, work buffers, a HIP stream."""
+    """One librrtmg_hip context: constants, device tables, work buffers, HIP streams.  Calls are serialised per context
+    (a re-entrant lock), so components sharing it may be driven from several Python threads."""
 
     def __init__(self, device=0):
         self.lib = load_library()
+        self._lock = threading.RLock()
+        self.deferred = False
         h = _vp()
         rc = self.lib.rrtmg_hip_create(C.byref(h), int(device))
         self.h = h
@@ -142,19 +160,24 @@ class Context:
         if rc:
             raise RRTMGError(rc, self.lib.rrtmg_hip_last_error(self.h).decode())
 
+    @_locked
     def set_constants(self, **k):
         self._ck(self.lib.rrtmg_hip_set_constants(self.h, *[float(k[n]) for n in CONSTANT_NAMES]))
 
+    @_locked
     def sw_init(self, cpdair, blob=None):
-        key = ("sw", float(cpdair), blob or SW_DATA)
+        blob = blob or os.environ.get("RRTMG_HIP_SW_DATA") or SW_DATA
+        key = ("sw", float(cpdair), blob)
         if getattr(self, "_sw_key", None) != key:       # (components sharing the context initialise the tables once)
-            self._ck(self.lib.rrtmg_hip_sw_init(self.h, float(cpdair), (blob or SW_DATA).encode()))
+            self._ck(self.lib.rrtmg_hip_sw_init(self.h, float(cpdair), blob.encode()))
             self._sw_key = key
 
+    @_locked
     def lw_init(self, cpdair, blob=None):
-        key = ("lw", float(cpdair), blob or LW_DATA)
+        blob = blob or os.environ.get("RRTMG_HIP_LW_DATA") or LW_DATA      # (a packed table file elsewhere: tools/ingest_lw_data.sh)
+        key = ("lw", float(cpdair), blob)
         if getattr(self, "_lw_key", None) != key:
-            self._ck(self.lib.rrtmg_hip_lw_init(self.h, float(cpdair), (blob or LW_DATA).encode()))
+            self._ck(self.lib.rrtmg_hip_lw_init(self.h, float(cpdair), blob.encode()))
             self._lw_key = key
 
     def lw_tables_synthetic(self):
@@ -164,38 +187,57 @@ class Context:
     def stream(self):
         return self.lib.rrtmg_hip_stream(self.h)
 
+    @_locked
     def kernel_ms(self, which, cloudy=False):
-        """HIP-event duration (ms) of the last solve launch: which = 'sw' | 'lw'; cloudy selects the kernel that handles
-        the cloudy tiles (sw_solve_cloudy_kernel / lw_solve_all_kernel<true,..>) instead of the clear-sky one."""
+        """HIP-event duration (ms) of a solve kernel in the last call, summed over the call's column chunks (one launch
+        each): which = 'sw' | 'lw'; cloudy selects the kernel that handles the cloudy tiles (sw_solve_cloudy_kernel /
+        lw_solve_all_kernel<true,..>) instead of the clear-sky one."""
         ms = C.c_double(0.0)
         self._ck(self.lib.rrtmg_hip_kernel_ms(self.h, (0 if which == "sw" else 1) + (2 if cloudy else 0), C.byref(ms)))
         return ms.value
 
+    @_locked
+    def kernel_launches(self, which, cloudy=False):
+        """Launches (column chunks) of that solve kernel in the last call; kernel_ms is their sum."""
+        return int(self.lib.rrtmg_hip_kernel_launches(self.h, (0 if which == "sw" else 1) + (2 if cloudy else 0)))
+
+    @_locked
+    def copy_blocks(self, desc_ptr, nblk, max_rows, max_cols, src, dst, stream=None):
+        """rrtmg_hip_copy_blocks: nblk strided 2-d block copies (device pointers; desc = device int64[nblk][6]) on `stream`."""
+        self._ck(self.lib.rrtmg_hip_copy_blocks(self.h, int(nblk), _vp(desc_ptr), int(max_rows), int(max_cols), _vp(src), _vp(dst), _vp(stream)))
+
+    @_locked
     def synchronize(self):
         """Wait for all enqueued work; in deferred mode this is where device-side errors are raised."""
         self._ck(self.lib.rrtmg_hip_synchronize(self.h))
 
+    @_locked
     def stream_wait(self, other_stream):
         """`other_stream` (hipStream_t) waits, on the device, for everything enqueued so far on this context's streams."""
         self._ck(self.lib.rrtmg_hip_stream_wait(self.h, _vp(other_stream)))
 
     # -- glue of the device-resident step (device pointers) ------------------------------------------
+    @_locked
     def interface_values(self, ncol, nlay, mid, surf, pmid, pint, out):
         self._ck(self.lib.rrtmg_hip_interface_values(self.h, int(ncol), int(nlay), mid, surf, pmid, pint, out))
 
+    @_locked
     def elementwise(self, op, n, a, out, b=None, alpha=1.0, beta=1.0):
         """op: 'axpby' out = alpha*a (+ beta*b), 'cos' out = cos(a), 'muldiv' out = a*alpha/beta"""
         self._ck(self.lib.rrtmg_hip_elementwise(self.h, {"axpby": 0, "cos": 1, "muldiv": 2}[op], int(n), a, b, float(alpha), float(beta), out))
 
+    @_locked
     def ab_step(self, n, x, tendencies, weights, dt, out):
         k = len(tendencies)
         f = (_vp * k)(*tendencies)
         w = (_f64 * k)(*weights)
         self._ck(self.lib.rrtmg_hip_ab_step(self.h, int(n), k, x, f, w, float(dt), out))
 
+    @_locked
     def order_streams(self, direction):
         self._ck(self.lib.rrtmg_hip_order_streams(self.h, int(direction)))
 
+    @_locked
     def slab_surface_device(self, ncol, ptrs, area_type, tend_ts, depth):
         """rrtmg_hip_slab_surface on device pointers: `ptrs` maps SLAB_IN names to device addresses."""
         a = SlabArgs()
@@ -204,6 +246,7 @@ class Context:
         a.area_type, a.tend_ts, a.depth = int(area_type), int(tend_ts), int(depth)
         self._ck(self.lib.rrtmg_hip_slab_surface(self.h, int(ncol), 1, C.byref(a)))
 
+    @_locked
     def zenith_angle(self, lat_deg, lon_deg, julian_centuries, out=None, memspace=0, ncol=None):
         """Zenith angle (radians) of every column; host arrays, or device pointers with memspace=1 (then `ncol`)."""
         if memspace:
@@ -215,6 +258,7 @@ class Context:
         self._ck(self.lib.rrtmg_hip_zenith_angle(self.h, lat.size, 0, lat.ctypes.data, lon.ctypes.data, float(julian_centuries), z.ctypes.data))
         return z
 
+    @_locked
     def solar_insolation(self, lat, lon, sin_delta, cos_delta, fractional_day, irradiance):
         """(zenith angle, insolation) of every column (host arrays): per-column part of BergerSolarInsolation."""
         lat = np.ascontiguousarray(lat, dtype=np.float64)
@@ -224,6 +268,7 @@ class Context:
                                                      float(fractional_day), float(irradiance), z.ctypes.data, s.ctypes.data))
         return z, s
 
+    @_locked
     def slab_surface(self, area_type, **arrays):
         """Kernel of climt SlabSurface on host arrays: -> (surface temperature tendency, slab depth).  `arrays`: SLAB_IN."""
         a = SlabArgs()
@@ -240,10 +285,17 @@ class Context:
         self._ck(self.lib.rrtmg_hip_slab_surface(self.h, n, 0, C.byref(a)))
         return tend, depth
 
+    @_locked
     def set_deferred(self, on=True):
-        """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams."""
+        """Device-resident (memspace=1) calls return after enqueueing; SW and LW overlap on two streams.  Returns the
+        previous setting, so that whoever switches it on for the lifetime of an object can restore it (the context is
+        shared: a memspace=1 caller that expects per-call synchronisation and error checks must get them back)."""
+        prev = self.deferred
         self._ck(self.lib.rrtmg_hip_set_deferred(self.h, 1 if on else 0))
+        self.deferred = bool(on)
+        return prev
 
+    @_locked
     def get_table(self, name):
         n = self.lib.rrtmg_hip_get_table(self.h, name.encode(), None, 0)
         if n < 0:
@@ -268,6 +320,7 @@ class Context:
                 keep.append(arr)
                 setattr(a, f, arr.ctypes.data)
 
+    @_locked
     def sw_fluxes(self, inp, mcica=False, out=None, memspace=0):
         nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
         a = SwArgs()
@@ -284,6 +337,7 @@ class Context:
         self._ck(self.lib.rrtmg_hip_sw_fluxes(self.h, C.byref(a)))
         return out
 
+    @_locked
     def lw_fluxes(self, inp, mcica=False, out=None, memspace=0):
         nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
         a = LwArgs()
@@ -302,6 +356,7 @@ class Context:
         self._ck(self.lib.rrtmg_hip_lw_fluxes(self.h, C.byref(a)))
         return out
 
+    @_locked
     def mcica_mask(self, which, play, cldfrac, icld, permuteseed, irng):
         nlay, ncol = play.shape
         nsub = 112 if which == "sw" else 140

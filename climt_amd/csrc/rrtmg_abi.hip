@@ -37,9 +37,6 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 2; ++k)
       if (!ctx->kiss_ev[w][k]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->kiss_ev[w][k], hipEventDisableTiming));
-  for (int w = 0; w < 4; ++w)
-    for (int k = 0; k < 2; ++k)
-      if (!ctx->ev[w][k]) RRTMG_HIP_CHECK(ctx, hipEventCreate(&ctx->ev[w][k]));
   for (int w = 0; w < 2; ++w)
     if (!ctx->sync_ev[w]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->sync_ev[w], hipEventDisableTiming));
   return RRTMG_OK;
@@ -127,8 +124,8 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
   if (ctx->err_dev) (void)hipFree(ctx->err_dev);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int w = 0; w < 4; ++w)
-    for (int k = 0; k < 2; ++k)
-      if (ctx->ev[w][k]) (void)hipEventDestroy(ctx->ev[w][k]);
+    for (hipEvent_t e : ctx->ev[w])
+      if (e) (void)hipEventDestroy(e);
   for (int w = 0; w < 2; ++w)
     for (int k = 0; k < 2; ++k)
       if (ctx->kiss_ev[w][k]) (void)hipEventDestroy(ctx->kiss_ev[w][k]);
@@ -144,12 +141,17 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
 const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 void *rrtmg_hip_stream(rrtmg_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms) {
-  if (!ctx || which < 0 || which > 3 || !ms || !ctx->ev_valid[which]) return RRTMG_ERR_ARG;
-  float f = 0.f;
-  RRTMG_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev[which][0], ctx->ev[which][1]));
-  *ms = (double)f;
+  if (!ctx || which < 0 || which > 3 || !ms || ctx->ev_chunks[which] <= 0) return RRTMG_ERR_ARG;
+  double sum = 0.0;
+  for (int c = 0; c < ctx->ev_chunks[which]; ++c) {
+    float f = 0.f;
+    RRTMG_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev[which][2 * c], ctx->ev[which][2 * c + 1]));
+    sum += (double)f;
+  }
+  *ms = sum;
   return RRTMG_OK;
 }
+int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which) { return (!ctx || which < 0 || which > 3) ? -1 : ctx->ev_chunks[which]; }
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
   if (!ctx) return RRTMG_ERR_ARG;
   if (ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -54,10 +54,20 @@ struct rrtmg_ctx {
   void *pinned = nullptr;
   size_t pinned_cap = 0;
   int *err_dev = nullptr;
-  // HIP events around the solve launches of the last column chunk: [0] sw clear-sky kernel, [1] lw clear-sky variant,
-  // [2] sw cloudy kernel, [3] lw cloudy variant; [start|stop]
-  hipEvent_t ev[4][2] = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
-  bool ev_valid[4] = {false, false, false, false};
+  // HIP events around the solve launches of EVERY column chunk of the last call: [0] sw clear-sky kernel, [1] lw clear-sky
+  // variant, [2] sw cloudy kernel, [3] lw cloudy variant; per chunk a (start, stop) pair, created on demand.
+  // rrtmg_hip_kernel_ms adds the chunks' durations up: the time that kernel took for ALL the call's columns.
+  std::vector<hipEvent_t> ev[4];
+  int ev_chunks[4] = {0, 0, 0, 0};   // chunks bracketed by the last call (0: that kernel was not launched)
+  hipEvent_t chunk_event(int which, int chunk, int side) {
+    std::vector<hipEvent_t> &v = ev[which];
+    while ((int)v.size() < 2 * (chunk + 1)) {
+      hipEvent_t e = nullptr;
+      if (hipEventCreate(&e) != hipSuccess) e = nullptr;
+      v.push_back(e);
+    }
+    return v[2 * chunk + side];
+  }
 
   int fail(int code, const char *fmt, ...) {
     char tmp[1024];

@@ -371,20 +371,20 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     d.col0 = t0 * 64; d.pcols = ctile * 64;
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
-    const bool last = t0 + ctile >= ntile;
-    if (last) (void)hipEventRecord(ctx->ev[1][0], s);
+    const int ci = t0 / ctile;
+    (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
     hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-    if (last) (void)hipEventRecord(ctx->ev[1][1], s);
+    (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
     if (clouds) {
-      if (last) (void)hipEventRecord(ctx->ev[3][0], s);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
       if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-      if (last) (void)hipEventRecord(ctx->ev[3][1], s);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
     }
     if (unfused_flux) hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
     else hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
-  ctx->ev_valid[1] = true; ctx->ev_valid[3] = clouds;
+  ctx->ev_chunks[1] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[3] = clouds ? ctx->ev_chunks[1] : 0;
   if (unfused_flux) hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

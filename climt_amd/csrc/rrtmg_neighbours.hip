@@ -244,6 +244,15 @@ __global__ void __launch_bounds__(256) ab_step_kernel(long n, int order, const d
   if (order > 3) incr = incr + w3 * f3[i];
   out[i] = x[i] + dt * incr;
 }
+// strided 2-d block copies (rrtmg_hip_copy_blocks): grid (column tiles of 256, row, block); rows of a block beyond its own
+// count and columns beyond its own width fall out.  Each row is a contiguous run on both sides: coalesced 8-byte accesses,
+// non-temporal (the gathered buffer is read once, the destination is not read by this kernel).
+__global__ void __launch_bounds__(256) copy_blocks_kernel(const int64_t *desc, const double *src, double *dst) {
+  const int64_t *q = desc + 6 * (long)blockIdx.z;
+  const long r = blockIdx.y, c = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= q[2] || c >= q[3]) return;
+  __builtin_nontemporal_store(__builtin_nontemporal_load(src + q[0] + r * q[4] + c), dst + q[1] + r * q[5] + c);
+}
 void launch_interface_values(hipStream_t s, int ncol, int nlay, const double *mid, const double *surf, const double *pmid, const double *pint, double *out) {
   hipLaunchKernelGGL(interface_values_kernel, dim3((ncol + 255) / 256, nlay + 1), dim3(256), 0, s, ncol, nlay, mid, surf, pmid, pint, out);
 }
@@ -290,5 +299,19 @@ extern "C" int rrtmg_hip_order_streams(rrtmg_ctx *ctx, int direction) {
   hipStream_t from = direction == 0 ? ctx->stream : ctx->stream_lw, to = direction == 0 ? ctx->stream_lw : ctx->stream;
   RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->sync_ev[direction ? 1 : 0], from));
   RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(to, ctx->sync_ev[direction ? 1 : 0], 0));
+  return RRTMG_OK;
+}
+
+extern "C" int rrtmg_hip_copy_blocks(rrtmg_ctx *ctx, int nblk, const int64_t *desc, long max_rows, long max_cols, const double *src, double *dst,
+                                     void *stream) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (nblk <= 0 || nblk > 65535 || max_rows <= 0 || max_rows > 65535 || max_cols <= 0 || !desc || !src || !dst)
+    return ctx->fail(RRTMG_ERR_ARG, "copy_blocks: bad argument");
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+  hipLaunchKernelGGL(copy_blocks_kernel, dim3((unsigned)((max_cols + 255) / 256), (unsigned)max_rows, (unsigned)nblk), dim3(256), 0, s, desc, src, dst);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred && !stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
   return RRTMG_OK;
 }

@@ -541,12 +541,12 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     d.col0 = t0 * 64; d.pcols = ctile * 64;
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
-    const bool last = t0 + ctile >= ntile;
-    if (last) (void)hipEventRecord(ctx->ev[0][0], s);
+    const int ci = t0 / ctile;
+    (void)hipEventRecord(ctx->chunk_event(0, ci, 0), s);
     hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, t0, nt);
-    if (last) (void)hipEventRecord(ctx->ev[0][1], s);
+    (void)hipEventRecord(ctx->chunk_event(0, ci, 1), s);
     if (clouds) {
-      if (last) (void)hipEventRecord(ctx->ev[2][0], s);
+      (void)hipEventRecord(ctx->chunk_event(2, ci, 0), s);
 #if !RRTMG_SWC_G4
       const int cgrp = (nt + kSwCldWgWaves - 1) / kSwCldWgWaves;
       const int cgrid = (RRTMG_SWC_XCD == 1 ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
@@ -556,12 +556,12 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 #else
       hipLaunchKernelGGL(sw_solve_cloudy_pairs_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
 #endif
-      if (last) (void)hipEventRecord(ctx->ev[2][1], s);
+      (void)hipEventRecord(ctx->chunk_event(2, ci, 1), s);
     }
     if (unfused_flux) hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
     else hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
-  ctx->ev_valid[0] = true; ctx->ev_valid[2] = clouds;
+  ctx->ev_chunks[0] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[2] = clouds ? ctx->ev_chunks[0] : 0;
   if (unfused_flux) hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -110,8 +110,23 @@ class DeviceState(dict):
                 continue          # produced by another component during the step (zenith angle, fluxes ...)
             self.put_host(name, state[name], prop)
         if deferred:
-            ctx.set_deferred(True)
+            self._prev_deferred = ctx.set_deferred(True)
         return self
+
+    def close(self):
+        """Collect the pending work and hand the (shared) context back in the mode it was found in: from_host switches the
+        context to deferred mode, which every other memspace=1 caller of the same context would otherwise inherit."""
+        prev = getattr(self, "_prev_deferred", None)
+        if prev is not None:
+            self.ctx.synchronize()
+            self.ctx.set_deferred(prev)
+            self._prev_deferred = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
 
     def put_host(self, name, da, prop):
         """Upload a host DataArray in the layout / units of `prop` (a component's input property)."""
@@ -403,13 +418,18 @@ class DeviceAdamsBashforth:
                     ctx.elementwise("axpby", q.size, q.ptr, acc.ptr, alpha=_rate(q.units))
                     total[name] = acc
         self._history = [total] + self._history[: self._order - 1]
-        weights = _AB[len(self._history)]
         dt = timestep.total_seconds()
         for name in total:
             old = ds[name]
-            hist = [h[name].ptr for h in self._history if name in h]
+            # the contiguous most-recent run of steps that carry a tendency for `name` sets the order for THAT quantity
+            # (the coefficients of an order sum to one; a truncated higher-order set would not)
+            hist = []
+            for h in self._history:
+                if name not in h:
+                    break
+                hist.append(h[name].ptr)
             new = ds.work(("ab", id(self), name, "state", ds.step_count % 2), old.shape, old.dims, old.units)
-            ctx.ab_step(old.size, old.ptr, hist, weights[: len(hist)], dt, new.ptr)
+            ctx.ab_step(old.size, old.ptr, hist, _AB[len(hist)], dt, new.ptr)
             ds[name] = new
         ds.step_count += 1
         if self._wait:

@@ -255,7 +255,7 @@ class ShardedRadiation:
             self.flat = [alloc((self.block,)) for _ in range(self.nbuf)]
             self.full = [alloc((self.block * self.world,)) if gathered_here else None for _ in range(self.nbuf)]
             self.events = [_hip.Event() for _ in range(self.nbuf)]
-            ctx.set_deferred(True)
+            self._prev_deferred = ctx.set_deferred(True)
         else:
             self.flat = [np.zeros(self.block) for _ in range(self.nbuf)]
             self.full = [np.zeros(self.block * self.world) if gathered_here else None for _ in range(self.nbuf)]

@@ -1,6 +1,6 @@
 """Keyword option -> RRTMG integer flag maps (same keys and values as
 climt/_components/rrtmg/rrtmg_common.py:7-59) and the shared library context."""
-import sys
+import weakref
 
 import numpy as np
 
@@ -47,27 +47,43 @@ def make_context(device):
 
 
 class OutputPool:
-    """Output arrays of earlier calls that NOBODY references any more are handed out again.
+    """Output buffers of earlier calls that NOBODY can see any more are handed out again.
 
     The reference allocates its outputs afresh on every call (initialize_numpy_arrays_with_properties), and so did this
     package -- but a fresh np.zeros array has no pages yet: the copy of the results into it takes a page fault per 4 KiB,
-    3-4 ms per LW+SW call at 8192 columns x 60 levels, a quarter of the drop-in call.  An array whose only reference is this
-    pool's (the caller dropped the DataArrays of that call, and every view of it) cannot be observed by anyone, so writing the
-    next call's results into it is indistinguishable from a fresh array -- except that its pages are mapped.  A caller that keeps
-    every result keeps getting fresh arrays.  Only for outputs the library overwrites completely (the radiation components')."""
+    3-4 ms per LW+SW call at 8192 columns x 60 levels, a quarter of the drop-in call.  A buffer whose every array view has
+    been garbage-collected cannot be observed by anyone, so writing the next call's results into it is indistinguishable
+    from a fresh array -- except that its pages are mapped.  A caller that keeps every result keeps getting fresh arrays.
+    Only for outputs the library overwrites completely (the radiation components').
+
+    Liveness is tracked explicitly, not through reference counts (whose values are an interpreter detail): the memory
+    belongs to a `bytearray`; each hand-out wraps it in a NEW root array (`np.frombuffer`), and what the caller receives
+    -- and every slice, reshape or DataArray made from it -- is a view whose `.base` chain ends at that root (numpy
+    collapses view chains to the first array whose own base is not an ndarray).  `weakref.finalize` on the root returns
+    the bytearray to the free list when the last such view has died; an interpreter that collects later only delays the
+    re-use."""
 
     def __init__(self, keep=4):
-        self._free, self._keep = {}, keep
+        self._free, self._keep, self._out = {}, keep, 0
+
+    def _release(self, key, backing):
+        self._out -= 1
+        lst = self._free.setdefault(key, [])
+        if len(lst) < self._keep:
+            lst.append(backing)
 
     def zeros_like_fresh(self, name, shape):
-        lst = self._free.setdefault((name, tuple(int(n) for n in shape)), [])
-        for a in lst:
-            if sys.getrefcount(a) == 3:      # the list's, the loop variable's, getrefcount's argument: no one else
-                return a
-        a = np.zeros(shape)
-        if len(lst) < self._keep:
-            lst.append(a)
-        return a
+        shape = tuple(int(n) for n in shape)
+        key = (name, shape)
+        lst = self._free.get(key)
+        if lst:
+            backing = lst.pop()
+        else:
+            backing = bytearray(8 * int(np.prod(shape)))      # zero-filled, pages touched
+        root = np.frombuffer(backing, dtype=np.float64)
+        weakref.finalize(root, self._release, key, backing)
+        self._out += 1
+        return root.reshape(shape)
 
 
 def output_arrays(pool, output_properties, raw_input_state, input_properties):

@@ -83,11 +83,16 @@ int rrtmg_hip_stream_wait(rrtmg_ctx *ctx, void *other_stream);
  * overlap on the GPU -- and the device-side error flags (the reference's `stop` conditions) are reported by the
  * next rrtmg_hip_synchronize / rrtmg_hip_set_deferred call instead.  Host-memory calls stay synchronous. */
 int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
-/* Duration (ms, HIP events recorded on the context's stream) of the dominant kernel of the last completed
- * call: which = 0 -> sw_solve_all_kernel<false> (clear-sky tiles), 1 -> lw_solve_all_kernel<false,..>, 2 -> sw_solve_cloudy_kernel,
- * 3 -> lw_solve_all_kernel<true,..>; each bracket holds exactly one launch (of the last column chunk), so the value is what
- * rocprofv3 reports for that kernel.  Returns RRTMG_ERR_ARG if that kernel was not launched by the last call. */
+/* Duration (ms, HIP events recorded on the stream the kernel is launched on) of a solve kernel in the last completed call:
+ * which = 0 -> sw_solve_all_kernel<false> (clear-sky tiles), 1 -> lw_solve_all_kernel<false,..>, 2 -> sw_solve_cloudy_kernel,
+ * 3 -> lw_solve_all_kernel<true,..>.  A call launches that kernel once per column chunk (RRTMG_HIP_CHUNK_TILES tiles of 64
+ * columns; one chunk up to 32768 columns); every launch has its own event bracket and the value is their SUM -- the time the
+ * kernel took for ALL the call's columns.  rrtmg_hip_kernel_launches returns the number of launches (chunks), so that
+ * sum / launches is the average launch duration rocprofv3 reports for that kernel (when the GPU is not shared with another
+ * stream: a bracket also contains the time its workgroups waited for compute units another stream's kernel held).
+ * RRTMG_ERR_ARG / 0 launches if that kernel was not launched by the last call. */
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
+int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which);
 
 /* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz,
@@ -145,6 +150,14 @@ int rrtmg_hip_elementwise(rrtmg_ctx *ctx, int op, long n, const double *a, const
 int rrtmg_hip_ab_step(rrtmg_ctx *ctx, long n, int order, const double *x, const double *const *f, const double *w, double dt, double *out);
 /* deferred mode: 0 = the longwave stream waits for the main stream's work so far, 1 = the main stream waits for the longwave's */
 int rrtmg_hip_order_streams(rrtmg_ctx *ctx, int direction);
+/* Strided copies of nblk two-dimensional blocks of doubles on the device, enqueued on `stream` (a hipStream_t of the caller;
+ * NULL = the context's main stream): block b copies rows x cols elements, dst[dst_off + r*dst_stride + c] = src[src_off +
+ * r*src_stride + c].  desc: DEVICE array of 6 int64 per block {src_off, dst_off, rows, cols, src_stride, dst_stride};
+ * max_rows / max_cols bound the launch.  Used to put an all-gathered output buffer -- [rank][array][level][local column] --
+ * into the boundary layout [array][level][column] (column fastest, rrtmg_lw_c_binder.f90:198-202) without leaving the GPU:
+ * climt_amd/distributed.py. */
+int rrtmg_hip_copy_blocks(rrtmg_ctx *ctx, int nblk, const int64_t *desc, long max_rows, long max_cols, const double *src, double *dst,
+                          void *stream);
 
 /* ---- shortwave ------------------------------------------------------------------------ */
 typedef struct rrtmg_sw_args {

@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-REFDIR = os.path.join(HERE, "_ref")
+REFDIR = os.environ.get("RRTMG_REF_DIR") or os.path.join(HERE, "_ref")   # (build_ref.sh: RRTMG_REF_OUT)
 
 # The reference's sub-column generators keep (ngpt, ncol, nlay) automatic arrays on the stack
 # (mcica_subcol_gen_sw.f90:317); lift the soft stack limit so a few hundred columns fit.
@@ -54,6 +54,17 @@ def _ri(x):
 
 def available(which="sw"):
     return os.path.exists(os.path.join(REFDIR, "librrtmg_%s_ref.so" % which))
+
+
+def lw_kdata():
+    """What the longwave reference library's k-distribution loaders lw_kgb01..16 are (oracle/build_ref.sh writes it
+    next to the library): "stub" -- oracle/lw_kg_stub.f90, empty loaders, the raw tables must be written into the
+    rrlw_kgNN module arrays before rrtmg_lw_ini (RefLW.init(fill_tables=...)) -- or "file <path> <sha256>" -- the
+    reference's data file rrtmg_lw_k_g.f90 was compiled in and rrtmg_lw_ini loads it itself."""
+    try:
+        return open(os.path.join(REFDIR, "lw_kdata.txt")).read().strip()
+    except OSError:
+        return "stub"          # libraries built before the marker existed were always linked with the stub
 
 
 def _cd(a):
@@ -172,7 +183,9 @@ class RefLW(_RefBase):
 
     def init(self, cpdair=CPDAIR, constants=CONSTANTS, fill_tables=None):
         """fill_tables(self) is called before rrtmg_lw_ini so that the raw (16-g) rrlw_kgNN
-        module arrays can be filled with synthetic data (the loaders lw_kgbNN are empty)."""
+        module arrays can be filled with synthetic data when the loaders lw_kgbNN are the empty stub
+        (lw_kdata() == "stub").  With the data file compiled in, the loaders overwrite whatever was
+        filled: the library then always runs on the file's tables."""
         k = constants
         self.lib.rrtmg_set_constants(*[_rd(k[n]) for n in (
             "pi", "grav", "planck", "boltz", "clight", "avogad", "alosmt", "gascon", "sbcnst", "secdy")])

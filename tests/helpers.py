@@ -67,9 +67,11 @@ class EmuContext:
 
     def lw_init(self, cpdair, blob=None):
         self.cpd_lw = cpdair
+        self.lw_blob = blob or os.environ.get("RRTMG_HIP_LW_DATA") or LW_DATA      # as climt_amd._lib.Context.lw_init
 
     def lw_tables_synthetic(self):
-        return True
+        from tools.pack_tables import read_blob      # the flag the product reads at init (rrtmg_tables.cpp: "lw/meta/synthetic")
+        return bool(int(np.ravel(read_blob(getattr(self, "lw_blob", LW_DATA)).get("lw/meta/synthetic", np.array([0])))[0]))
 
     def close(self):
         pass
@@ -106,7 +108,7 @@ class EmuContext:
         for k in out:
             setattr(a, k, out[k].ctypes.data)
         eb = C.create_string_buffer(512)
-        rc = self.lib.emu_lw_fluxes(C.byref(a), LW_DATA.encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
+        rc = self.lib.emu_lw_fluxes(C.byref(a), getattr(self, "lw_blob", LW_DATA).encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
         if rc:
             from climt_amd._lib import RRTMGError
             raise RRTMGError(rc, eb.value.decode())

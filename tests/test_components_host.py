@@ -257,18 +257,31 @@ def test_output_pool_never_hands_out_an_array_somebody_still_holds():
     and a recycled array must be indistinguishable from that."""
     from climt_amd.rrtmg.common import OutputPool, output_arrays
     pool = OutputPool()
+
+    def mem(x):
+        return x.__array_interface__["data"][0]
     a = pool.zeros_like_fresh("x", (3, 4))
     b = pool.zeros_like_fresh("x", (3, 4))
-    assert a is not b and not a.any()                      # `a` is held: a new array
-    ida = id(a)
-    view = a[1]                                            # a view keeps its base alive through .base
-    del a
+    assert mem(a) != mem(b) and not a.any()                # `a` is held: other memory
+    mem_a = mem(a)
+    a[:] = 7.0
+    view = a[1]                                            # a view keeps the hand-out alive through its .base chain
+    held = [a]                                             # ... and so does any other reference (the advisor's case:
+    del a                                                  # an interpreter whose reference counts read differently)
     c = pool.zeros_like_fresh("x", (3, 4))
-    assert id(c) != ida and c is not b
+    assert mem(c) not in (mem_a, mem(b))
+    del held[:]
+    e = pool.zeros_like_fresh("x", (3, 4))                 # the slice `view` is still alive
+    assert mem(e) not in (mem_a, mem(b), mem(c)) and (view == 7.0).all()
+    flat = view.reshape(-1)[::2]                           # views of views end at the same root
     del view
+    f = pool.zeros_like_fresh("x", (3, 4))
+    assert mem(f) != mem_a and (flat == 7.0).all()
+    del flat
     d = pool.zeros_like_fresh("x", (3, 4))
-    assert id(d) == ida                                    # nobody holds it any more: handed out again
-    assert pool.zeros_like_fresh("x", (4, 3)).shape == (4, 3) and pool.zeros_like_fresh("y", (3, 4)) is not d
+    assert mem(d) == mem_a                                 # nobody can see it any more: handed out again
+    assert pool.zeros_like_fresh("x", (4, 3)).shape == (4, 3) and mem(pool.zeros_like_fresh("y", (3, 4))) != mem(d)
+    assert d.flags.writeable and d.flags.c_contiguous and d.dtype == np.float64
     # shapes as initialize_numpy_arrays_with_properties derives them
     props_in = {"t": {"dims": ["mid_levels", "*"], "units": "K"}, "p": {"dims": ["interface_levels", "*"], "units": "Pa"}}
     raw = {"t": np.zeros((5, 7)), "p": np.zeros((6, 7))}

@@ -11,11 +11,18 @@ rrsw_aer.f90, rrsw_ref.f90, rrsw_wvn.f90, and the rrlw_* equivalents) at pack ti
 
   SW blob  : RAW 16-g tables (kao, kbo, selfrefo, ... from rrtmg_sw_k_g.f90) + small tables.
              The 224->112 g-point reduction is done by the product at init (csrc/tables.cpp).
-  LW blob  : the reference's LW k-data file (rrtmg_lw_k_g.f90) is a missing blob, so the RAW
-             k-tables in the LW blob are SYNTHETIC (tools/synth_lw_tables.py; flagged by the
-             entry "lw/meta/synthetic" = 1); every in-tree small table (Planck totplnk,
-             chi_mls, cloud tables, reduction bookkeeping) is real.  A real LW blob can be
-             produced with the same tool once the data file exists (no code change).
+  LW blob  : RAW 16-g tables as the compiled reference library holds them after rrtmg_lw_ini, plus
+             every in-tree small table (Planck totplnk, chi_mls, cloud tables, reduction
+             bookkeeping).  Where the raw tables come from depends on how oracle/build_ref.sh linked
+             the library (oracle/_ref/lw_kdata.txt):
+               "file ..." the reference's data file rrtmg_lw_k_g.f90 was compiled in: its loaders
+                          lw_kgb01..16 filled the module arrays -> "lw/meta/synthetic" = 0;
+               "stub"     the file is a missing blob (this checkout): empty loaders, the module arrays
+                          are filled with SYNTHETIC tables (tools/synth_lw_tables.py) before
+                          rrtmg_lw_ini -> "lw/meta/synthetic" = 1.
+             tools/ingest_lw_data.sh <rrtmg_lw_k_g.f90> runs the whole chain for a real file.
+
+  python tools/pack_tables.py [sw|lw|all] [--out <blob>] [--fixture-out <npz>]   (defaults: the shipped paths)
 
 Container: magic "RRTBL001", u32 count, then per entry
    u32 namelen, name, u32 dtype(0=f64,1=i32), u32 ndim, u32 dims[ndim] (Fortran order,
@@ -219,13 +226,18 @@ def pack_sw():
     print("SW blob:", out, os.path.getsize(out), "bytes;", len(blob.entries), "entries; reduced fixture:", len(red))
 
 
-def pack_lw():
+def pack_lw(out=None, fixture_out=None):
+    from oracle import ref_driver
     from oracle.ref_driver import RefLW
     from tools.synth_lw_tables import fill_reference_modules
     libdir = os.path.join(REF, "climt/_lib/rrtmg_lw")
     par = parse_params(os.path.join(libdir, "parrrtm.f90"))
     ref = RefLW()
-    ref.init(fill_tables=lambda r: fill_reference_modules(r, libdir, par))
+    kdata = ref_driver.lw_kdata()
+    if kdata == "stub":
+        ref.init(fill_tables=lambda r: fill_reference_modules(r, libdir, par))
+    else:
+        ref.init()      # the library's own loaders (the reference's data file) fill the raw tables
     mods = ["rrlw_kg%02d.f90" % b for b in range(1, 17)] + ["rrlw_cld.f90", "rrlw_ref.f90", "rrlw_wvn.f90"]
     keep, reduced = dump_modules(ref, libdir, "lw", mods, par)
     blob = Blob()
@@ -234,21 +246,38 @@ def pack_lw():
             reduced[k] = (a, dims)
             continue
         blob.add(k, a, dims)
-    blob.add("lw/meta/synthetic", np.array([1], dtype=np.int32))
-    out = os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin")
+    if kdata != "stub":
+        kao = keep["lw/kg01/kao"][0]
+        if not np.any(kao != 0.0):
+            raise SystemExit("pack_lw: the library says its k-data come from '%s' but lw/kg01/kao is all zero" % kdata)
+    blob.add("lw/meta/synthetic", np.array([1 if kdata == "stub" else 0], dtype=np.int32))
+    out = out or os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin")
     blob.write(out)
     red = {k.replace("/", "__"): a for k, (a, d) in reduced.items()}
     for t in ("exp_tbl", "tau_tbl", "tfn_tbl"):
         red["lw__tbl__" + t] = np.array(ref.module_array("rrlw_tbl", t, (10001,)))
     red["lw__con__heatfac"] = np.array(ref.module_scalar("rrlw_con", "heatfac"))
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "lw_reduced_tables.npz"), **red)
-    print("LW blob:", out, os.path.getsize(out), "bytes;", len(blob.entries), "entries; reduced fixture:", len(red))
+    fixture_out = fixture_out or os.path.join(ROOT, "tests", "golden", "lw_reduced_tables.npz")
+    np.savez_compressed(fixture_out, **red)
+    print("LW blob:", out, os.path.getsize(out), "bytes;", len(blob.entries), "entries; reduced fixture:", len(red),
+          "; k-data:", kdata, "-> synthetic =", 1 if kdata == "stub" else 0)
 
 
 if __name__ == "__main__":
-    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    argv = sys.argv[1:]
+    opts = {}
+    for flag in ("--out", "--fixture-out"):
+        if flag in argv:
+            i = argv.index(flag)
+            opts[flag] = argv[i + 1]
+            del argv[i:i + 2]
+    what = argv[0] if argv else "all"
+    if opts and what == "all":
+        raise SystemExit("--out / --fixture-out need an explicit 'sw' or 'lw'")
     os.makedirs(os.path.join(ROOT, "tests", "golden"), exist_ok=True)
     if what in ("sw", "all"):
+        if opts:
+            raise SystemExit("--out / --fixture-out are implemented for 'lw' only")
         pack_sw()
     if what in ("lw", "all"):
-        pack_lw()
+        pack_lw(opts.get("--out"), opts.get("--fixture-out"))
