@@ -14,11 +14,20 @@ through ctypes, all-gather of one flat double-buffered device buffer on its own 
 gather is inside the timed region.  torch is used ONLY for the launch contract (process group, barrier, max over ranks) and
 as a fallback communicator if librccl cannot be initialised; the compute path is librrtmg_hip.so through ctypes.
 
+`python bench.py --gpus N` with N > 1 and no launcher (no WORLD_SIZE in the environment) starts the N ranks itself, one process
+per GPU, exactly as the driver's `torch.distributed.run` line would; it refuses to run when the box has fewer GPUs.
+
 Prints ONE JSON line on rank 0 (see the driver contract), with
-  roofline     : dominant kernel = the longer of the SW / LW solve kernels, duration from HIP events recorded on the library's
-                 stream around that launch (rrtmg_hip_kernel_ms); achieved = algorithmic bytes of that half (SW (34L+11)*8 B,
-                 LW (56L+22)*8 B per column, SURVEY.md 8d) x columns per launch / duration, peak = 8 TB/s HBM3E;
-                 traffic / fp64_frac from the PMC passes committed under profiles/ (same command).
+  roofline     : dominant kernel = the solve kernel (SW or LW) that takes longer WITH THE GPU TO ITSELF (HIP events around its
+                 launches on the stream it runs on, rrtmg_hip_kernel_ms; that is also the order of the kernels' shares in
+                 profiles/*_kernel_stats.txt); achieved = its ALGORITHMIC bytes per launch (SW (34L+11)*8 B, LW (56L+22)*8 B
+                 per column, SURVEY.md 8d, x columns per launch) / its average launch duration; a call launches a solve
+                 kernel once per chunk of <= 32768 columns, durations are summed over the chunks and divided by their
+                 number; peak = 8 TB/s HBM3E.  roofline.kernels lists BOTH solve kernels with their durations in the timed
+                 region (SW || LW: a bracket there also holds the time workgroups waited for CUs the other stream held)
+                 and alone, bytes, traffic (FETCH x 2 + WRITE from the PMC passes under profiles/) and FP64 flops;
+                 step_traffic = the same counters summed over EVERY kernel of a step, step_hbm_side_frac = that / ms_per_step
+                 / 6.3 TB/s (what this part sustains): how close the step is to a floor made of bytes it moves.
   cpu_baseline : the reference Fortran (oracle/_ref; LW on the synthetic k-tables) timed on the host cores of this box on a
                  bounded sample of the same columns (rank 0, N=1 only).
   extra        : (N=1) the McICA configuration in the same run, and the end-to-end rates that include PCIe: the host-pointer
@@ -39,6 +48,7 @@ CONSTANTS = dict(pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852
                  avogad=6.022140857e23, alosmt=2.6867774e19, gascon=8.3144598e7, sbcnst=5.670367e-12, secdy=86400.0)
 CPDAIR = 1004.64
 HBM_PEAK = 8.0e12
+HBM_SUSTAINED = 6.3e12     # what a streaming kernel achieves on this part (MI355X_MICROARCH.md; the flux kernels reach 4.3-4.5e12)
 FP64_PEAK = 78.6e12     # vector FP64, MI355X_MICROARCH.md
 FLAGS = dict(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
 
@@ -152,6 +162,21 @@ class _TorchDeviceComm:
         pass
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks (this script, RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* set as torch.distributed.run sets them), rank 0 prints the line, the exit code is the worst rank's."""
+    import socket
+    import subprocess
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rcs = [p.wait() for p in procs]
+    sys.exit(max(abs(rc) for rc in rcs))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +197,11 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (2 ranks on a 1-GPU box; with --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (communicator, gather) with a single rank too")
+    ap.add_argument("--no-unpack", action="store_true", help="N>1: leave the gathered outputs in the collective's layout [rank][array][level][local column] "
+                    "(default: a block-copy kernel behind the gather writes the boundary layout [array][level][column])")
+    ap.add_argument("--rccl-channels", type=int, default=16, help="N>1: NCCL_MAX_NCHANNELS for the gather (each channel occupies a CU while it runs; "
+                    "0 = RCCL's default; a value already in the environment wins)")
+    ap.add_argument("--min-seconds", type=float, default=3.0, help="timed region: brackets of K steps are repeated until this much time is covered")
     a = ap.parse_args()
     preset = {2: (8192, 60, False), 3: (8192, 60, True), 4: (16384, 60, True), 5: (129600, 100, True)}[a.config]
     N = a.columns or preset[0]
@@ -180,12 +210,22 @@ def main():
     if a.no_gather:
         a.gather = "none"
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from climt_amd import _hip as _h
+        have = _h.device_count()
+        if have < a.gpus and not a.share_device:
+            sys.stderr.write("bench.py: --gpus %d asked for, this box has %d GPU(s): refusing to measure fewer GPUs than asked for "
+                             "(run with a --gpus the box has; --share-device puts every rank on GPU 0 for testing)\n" % (a.gpus, have))
+            sys.exit(2)
+        spawn_ranks(a.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = 0 if "--share-device" in sys.argv else int(os.environ.get("LOCAL_RANK", "0"))
     multi = world > 1 or a.force_dist
     if world > 1:
         a.gpus = world
+    if world != max(1, a.gpus):      # (cannot happen: a launcher's WORLD_SIZE overrides --gpus above)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (a.gpus, world))
     dist = None
     if multi:
         import torch
@@ -199,6 +239,10 @@ def main():
         # torch's process group creates streams of its own before the context creates its two: with the runtime's default of
         # four hardware queues the SW and LW streams then share one and the step loses its overlap (2.00 vs 1.76 ms)
         os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+        # RCCL's kernels take one compute unit per channel while a gather runs, next to solve kernels that fill every CU
+        # (sw_solve_all_kernel<false> is one round of one workgroup per CU): bound them; the line says how many were allowed
+        if a.rccl_channels > 0:
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(a.rccl_channels))
         torch.cuda.set_device(local)
         if a.dist_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -299,14 +343,14 @@ def main():
         return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0])
 
     def reps_of(k, ncol, nlay, cld):
-        """Brackets of exactly k steps needed for >= 1 s of timed region (1 when k was chosen by pick_steps)."""
+        """Brackets of exactly k steps needed for >= --min-seconds of timed region."""
         est = ncol * (nlay / 60.0) / (2.7e6 if cld else 5.4e6)
-        return int(max(1, min(400, np.ceil(1.2 / (k * est)))))
+        return int(max(1, min(1000, np.ceil(a.min_seconds * 1.1 / (k * est)))))
 
     def pick_steps(ncol, nlay, cld):
-        """Enough steps for >= 1 s of timed region (estimated from the large-grid rates of DESIGN.md 5)."""
+        """Steps per bracket: about 1.5 s worth (estimated from the large-grid rates of DESIGN.md 5); brackets repeat to --min-seconds."""
         est = ncol * (nlay / 60.0) / (2.7e6 if cld else 5.4e6)
-        return max(10, int(np.ceil(1.2 / est)))
+        return max(10, int(np.ceil(min(a.min_seconds, 1.5) * 1.1 / est)))
 
     steps = a.steps if a.steps is not None else pick_steps(N, L, cloudy)
     warmup = a.warmup if a.warmup is not None else max(2, min(10, steps // 20))
@@ -357,7 +401,7 @@ def main():
             comm = _TorchDeviceComm(dist, rank, world, "cuda:%d" % local)
             alloc = comm.alloc
         comm_kind = comm.kind
-        sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist)
+        sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist, unpack=not a.no_unpack)
         if a.serial:
             ctx.set_deferred(False)
         sr.set_inputs(columns(N, L, cloudy), already_local=True)
@@ -402,24 +446,70 @@ def main():
             ksw.append(ctx.kernel_ms("sw", cloudy=cloudy))
             klw.append(ctx.kernel_ms("lw", cloudy=cloudy))
         fence()
-        r = dict(ksw=ksw, klw=klw, ssw=ksw, slw=klw, enq_sw=0.0, enq=0.0, brackets=brackets)
+        # the same brackets WITHOUT the gather (and its unpack): compute scaling and gather cost become separable in ONE run
+        gather_none = None
+        if sr.do_gather:
+            had, sr.do_gather = True, False
+            nb = []
+            for _ in range(max(1, reps_of(steps, N, L, cloudy) // 2)):
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(steps):
+                    step(sync=a.serial or a.sync_every_step)
+                fence()
+                t = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], dtype=torch.float64, device="cuda:%d" % local)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                nb.append(float(t.item()))
+            sr.do_gather = had
+            gather_none = {"value": world * N / (float(np.median(nb)) * 1e-3), "unit": "columns/s", "ms_per_step": float(np.median(nb)), "brackets": len(nb),
+                           "note": "same run, same K-step brackets (barrier + synchronize on both sides, max over ranks), the output gather and its "
+                                   "unpack switched off: value / this value = what the gather costs"}
+        # the two solve kernels with the GPU to themselves (synchronous SW then LW calls on this rank's block)
+        fence()
+        ctx.set_deferred(False)
+        sw_o, lw_o = sr._out(0)
+        ssw, slw = [], []
+        for _ in range(3):
+            ctx.sw_fluxes(sr.inp, mcica=cloudy, out=sw_o, memspace=1)
+            ctx.lw_fluxes(sr.inp, mcica=cloudy, out=lw_o, memspace=1)
+            ssw.append(ctx.kernel_ms("sw", cloudy=cloudy))
+            slw.append(ctx.kernel_ms("lw", cloudy=cloudy))
+        fence()
+        r = dict(ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=0.0, enq=0.0, brackets=brackets, gather_none=gather_none)
         if gather_error:
             comm_note += "output gather FAILED and was switched off (%s); " % gather_error[0]
     value = world * N / (ms * 1e-3)
 
     res = None
     if rank == 0:
-        sw_ms, lw_ms = float(np.mean(r["ksw"])), float(np.mean(r["klw"]))
-        # the cloudy / clear-sky instantiation that does the work (names as rocprofv3 prints them)
-        if sw_ms >= lw_ms:
-            kname, kms, bpc = ("rrtmg::sw_solve_cloudy_kernel" if cloudy else "rrtmg::sw_solve_all_kernel<false>"), sw_ms, (34 * L + 11) * 8
-        else:
-            kname, kms, bpc = "rrtmg::lw_solve_all_kernel" + ("<true, false>" if cloudy else "<false, false>"), lw_ms, (56 * L + 22) * 8
-        achieved = bpc * N / (kms * 1e-3) / 1e9
-        kms_serial = float(np.mean(r["ssw"] if sw_ms >= lw_ms else r["slw"]))      # the same kernel with the GPU to itself
-        key = "%s|%d|%d|%s" % (kname, N, L, "cloudy" if cloudy else "clear")
-        traffic = _profile_json("hbm_traffic.json").get(key)
-        flops = _profile_json("fp64_flops.json").get(key)      # FP64 flops per launch from the SQ instruction counters
+        mode = "cloudy" if cloudy else "clear"
+        traffic_json, flops_json = _profile_json("hbm_traffic.json"), _profile_json("fp64_flops.json")
+        launches = max(1, ctx.kernel_launches("sw", cloudy=cloudy))      # column chunks per call: one launch of each solve kernel per chunk
+        kernels = []
+        for which, first, name, bpc, timed, alone in (
+                ("sw", not a.lw_first, "rrtmg::sw_solve_cloudy_kernel" if cloudy else "rrtmg::sw_solve_all_kernel<false>", (34 * L + 11) * 8, r["ksw"], r["ssw"]),
+                ("lw", a.lw_first, "rrtmg::lw_solve_all_kernel" + ("<true, false>" if cloudy else "<false, false>"), (56 * L + 22) * 8, r["klw"], r["slw"])):
+            t_ms, s_ms = float(np.mean(timed)), float(np.mean(alone))      # each: sum over the call's chunks
+            key = "%s|%d|%d|%s" % (name, N, L, mode)
+            tr, fl = traffic_json.get(key), flops_json.get(key)
+            kernels.append({
+                "kernel": name, "launches_per_step": launches, "columns_per_launch": N / launches, "algorithmic_bytes_per_column": bpc,
+                "algorithmic_bytes_per_launch": bpc * N / launches,
+                "launch_ms_timed_region": t_ms / launches, "launch_ms_alone": s_ms / launches, "enqueued_first": bool(first),
+                "achieved_GBps_alone": bpc * N / (s_ms * 1e-3) / 1e9, "frac_alone": bpc * N / (s_ms * 1e-3) / HBM_PEAK,
+                "achieved_GBps_timed_region": bpc * N / (t_ms * 1e-3) / 1e9, "frac_timed_region": bpc * N / (t_ms * 1e-3) / HBM_PEAK,
+                "traffic_per_launch": tr, "traffic_over_algorithmic": (tr / (bpc * N / launches)) if tr else None,
+                "fp64_flops_per_launch": fl, "fp64_frac_alone": (fl / (s_ms / launches * 1e-3) / FP64_PEAK) if fl else None})
+        dom = max(kernels, key=lambda k: k["launch_ms_alone"])      # the kernel that takes longer with the GPU to itself
+        # Its launch duration IN THE TIMED REGION is free of queueing when its spectrum is enqueued first (it starts on CUs
+        # nobody holds); otherwise the bracket would also count the wait for the other stream's workgroups: take it alone.
+        src = "timed_region" if (dom["enqueued_first"] or a.serial) else "alone"
+        kname, kms, bpc = dom["kernel"], dom["launch_ms_" + src], dom["algorithmic_bytes_per_column"]
+        kms_serial = dom["launch_ms_alone"]
+        achieved = dom["algorithmic_bytes_per_launch"] / (kms * 1e-3) / 1e9
+        traffic, flops = dom["traffic_per_launch"], dom["fp64_flops_per_launch"]
+        sw_ms, lw_ms = kernels[0]["launch_ms_timed_region"], kernels[1]["launch_ms_timed_region"]
+        step_traffic = traffic_json.get("step|%d|%d|%s" % (N, L, mode))      # FETCH x 2 + WRITE summed over every kernel of a step
         par = "columns sharded x%d" % world
         if world > 1:
             par += {"all": " + RCCL all-gather of the outputs (one flat buffer, double-buffered: runs under the next step's kernels)",
@@ -441,24 +531,39 @@ def main():
                        "ms_per_step_p10_p90": [float(np.percentile(per, 10)), float(np.percentile(per, 90))],
                        "lw_k_tables": "synthetic (reference LW data file missing)", "sw_k_tables": "reference"},
             "roofline": {"bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms,
-                         "algorithmic_bytes_per_column": bpc, "sw_solve_ms": sw_ms, "lw_solve_ms": lw_ms,
-                         "sw_solve_ms_serial": float(np.mean(r["ssw"])), "lw_solve_ms_serial": float(np.mean(r["slw"])),
-                         "kernel_ms_serial": kms_serial, "frac_serial": bpc * N / (kms_serial * 1e-3) / HBM_PEAK,
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms, "duration_source": src,
+                         "launches_per_step": launches, "columns_per_launch": N / launches,
+                         "algorithmic_bytes_per_column": bpc, "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"],
+                         "sw_solve_ms": sw_ms, "lw_solve_ms": lw_ms,
+                         "sw_solve_ms_serial": kernels[0]["launch_ms_alone"], "lw_solve_ms_serial": kernels[1]["launch_ms_alone"],
+                         "kernel_ms_serial": kms_serial, "frac_serial": dom["frac_alone"],
+                         "kernels": kernels,
                          # the whole LW+SW step: its algorithmic bytes ((34L+11)*8 SW + (56L+22)*8 LW per column)
-                         # over the step time -- the two solve kernels share the GPU in the timed region, so the duration of
-                         # either one alone there says how the scheduler split the CUs, not how fast the path is
+                         # over the step time, and the bytes it actually moves against what the memory system sustains
                          "step_algorithmic_bytes_per_column": (34 * L + 11) * 8 + (56 * L + 22) * 8,
                          "step_frac": ((34 * L + 11) * 8 + (56 * L + 22) * 8) * N / (ms * 1e-3) / HBM_PEAK,
+                         "step_traffic": step_traffic,
+                         "step_traffic_over_algorithmic": (step_traffic / (((34 * L + 11) * 8 + (56 * L + 22) * 8) * N)) if step_traffic else None,
+                         "step_hbm_side_frac": (step_traffic / (ms * 1e-3) / HBM_SUSTAINED) if step_traffic else None,
+                         "step_hbm_side_frac_of_peak": (step_traffic / (ms * 1e-3) / HBM_PEAK) if step_traffic else None,
                          "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
                          "fp64_frac_serial": (flops / (kms_serial * 1e-3) / FP64_PEAK) if flops else None,
                          "host_call_ms": {"sw": r["enq_sw"], "sw+lw": r["enq"]},
-                         "note": "achieved/frac: ALGORITHMIC bytes over the event-timed duration in the timed region (SW and LW kernels overlap "
-                                 "there); `traffic` = measured HBM bytes per launch and `fp64_flops_per_launch` = measured FP64 flops per launch "
-                                 "(PMC passes of this command, profiles/); the path is 108 FLOP/B on algorithmic bytes: FP64-issue / latency "
-                                 "bound, not HBM bound (fp64_frac is the fraction of the 78.6 TF vector peak)"},
+                         "note": "kernel = the solve kernel that takes longer with the GPU to itself (also the larger share in profiles/*_kernel_stats.txt); "
+                                 "achieved = its ALGORITHMIC bytes per launch / kernel_ms (HIP events around its launches, average over the launches "
+                                 "of a call; duration_source says whether that is the timed region or the kernel alone); kernels[] has both solve "
+                                 "kernels either way.  traffic / step_traffic = measured HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, PMC passes of "
+                                 "this command committed under profiles/); step_hbm_side_frac = step_traffic / ms_per_step / 6.3 TB/s.  The path is "
+                                 "108 FLOP/B on algorithmic bytes: FP64-issue / latency bound, not HBM bound (fp64_frac: of the 78.6 TF vector peak)"},
         }
         res["cpu_baseline"] = None
+        if multi:
+            res["config"]["rccl_max_channels"] = os.environ.get("NCCL_MAX_NCHANNELS")
+            res["config"]["gathered_layout"] = ("boundary [array][level][column] (block-copy kernel behind the gather)" if sr.unpack else
+                                                "collective [rank][array][level][local column]") if sr.do_gather else None
+            res["extra"] = {"gather_none": r.get("gather_none"),
+                            "how_to_scale": "per-GPU work is fixed (weak scaling): `--config 4` = 512x256x60 over 8 GPUs (16384 columns each), `--config 5` = "
+                                            "1440x720x100 (129600 columns x 100 levels each); `--gather none|root|all`, `--no-unpack`, `--rccl-channels N`"}
         if world == 1 and not multi:
             if not a.no_extra:
                 extra = {}

@@ -166,6 +166,41 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   lw_solve_item<CLD, MR, kLdsK>(d, T, item, col, scr, 64, sink, sh_k);
 }
 
+#ifdef RRTMG_LW_MERGED
+// Experiment: BOTH variants in one launch -- every wavefront takes the clear-sky or the cloudy code by its own tile's flag
+// (wave-uniform), so cloud-free and cloudy tiles of a grid run side by side instead of one launch after the other, and a grid
+// with only one kind of tile does not pay for a launch that finds nothing to do.
+template <bool MR>
+__global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_merged_kernel(LwDev d, LwTab T, int tile0, int ntile) {
+  const int q = blockIdx.x;
+  const int per = kLwGroupBlocks * T.nitem;
+  const int grp = q / per, r = q % per;
+  const int k = r / kLwGroupBlocks;
+  const int ctile0 = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;
+  if (ctile0 >= ntile) return;
+  const int slot = T.sched[k], item = T.item[slot];
+  const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
+  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * RRTMG_LW_GMAX];
+  {
+    const LwBandTab &B = T.b[item & 0xff];
+    const double *src = T.t + B.slab + ig0;
+    const int ng = B.ng, sh = g == 8 ? 3 : g == 4 ? 2 : 1, n = B.nrows << sh;
+    for (int i = threadIdx.x; i < n; i += 64 * kLwWgWaves) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
+  }
+  __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ctile = ctile0 + wave, tile = tile0 + ctile;
+  if (ctile >= ntile) return;
+  const int lane = threadIdx.x & 63;
+  const int col = tile * 64 + lane;
+  if (col >= d.ncol) return;
+  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * g);
+  LwPartSink sink = lw_part_sink(d, slot, col);
+  if (__builtin_amdgcn_readfirstlane(d.tile_cld[tile]) != 0) lw_solve_item<true, MR, true>(d, T, item, col, scr, 64, sink, sh_k);
+  else lw_solve_item<false, false, true>(d, T, item, col, scr, 64, sink, sh_k);
+}
+#endif
+
 __global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T, int tile0) {
   const int col = (tile0 + blockIdx.x) * 64 + threadIdx.x;
   if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem, d.tile_cld[tile0 + blockIdx.x] != 0);
@@ -311,6 +346,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     if (d.idrv) { d.duflx_dt = wd("o.du", nl1); d.duflxc_dt = wd("o.duc", nl1); }
   }
   if (!ok) return ctx->status;
+#ifdef RRTMG_LW_PHASES
+  d.phase = (unsigned long long *)ctx->buf("lw.w.phase", 16 * 8);
+  if (!d.phase) return ctx->status;
+  RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.phase, 0, 16 * 8, s));
+#endif
   d.err = ctx->err_dev + 1;   // [0] shortwave, [1] longwave
   const bool deferred_call = ctx->deferred && a->memspace == 1;
   if (!deferred_call) {
@@ -372,10 +412,26 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const int ci = t0 / ctile;
+#ifdef RRTMG_LW_MERGED
+    if (clouds) {
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
+      if (maxrand) hipLaunchKernelGGL((lw_solve_merged_kernel<true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      else hipLaunchKernelGGL((lw_solve_merged_kernel<false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
+    } else {
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
+      hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
+    }
+    if (false) {
+#else
     (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
     hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
     (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
     if (clouds) {
+#endif
       (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
       if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
@@ -387,6 +443,20 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   ctx->ev_chunks[1] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[3] = clouds ? ctx->ev_chunks[1] : 0;
   if (unfused_flux) hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
+#ifdef RRTMG_LW_PHASES
+  {
+    unsigned long long ph[16];
+    RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+    RRTMG_HIP_CHECK(ctx, hipMemcpy(ph, d.phase, sizeof ph, hipMemcpyDeviceToHost));
+    static const char *nm[8] = {"setup", "prep rows", "taumol", "planck+rows", "lookups+recurrence", "stores", "surface+up sweep", "-"};
+    const double w = ph[8] ? (double)ph[8] : 1.0;
+    fprintf(stderr, "lw phases (s_memtime ticks per wave-item, %llu waves, %d layers):", ph[8], L);
+    for (int k = 0; k < 7; ++k) fprintf(stderr, " %s %.0f;", nm[k], ph[k] / w);
+    fprintf(stderr, "\n  per layer of the downward sweep:");
+    for (int k = 1; k <= 5; ++k) fprintf(stderr, " %s %.0f", nm[k], ph[k] / w / L);
+    fprintf(stderr, "; up sweep per layer %.0f\n", ph[6] / w / L);
+  }
+#endif
 
   if (ctx->deferred && a->memspace == 1) { ctx->pending[1] = true; ctx->status = 0; return RRTMG_OK; }
   int herr = 0;

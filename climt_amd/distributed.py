@@ -7,6 +7,9 @@ exchanged while computing.  The only communication reassembles the outputs, and 
     gather = "all"   one ncclAllGather of a flat device buffer holding the rank's 12 (14 with dF/dT) output arrays
              "root"  the blocks are sent to rank 0 only (grouped ncclSend / ncclRecv)
              "none"  every rank keeps its block (a model that is itself domain-decomposed needs nothing else)
+    unpack = True    the gathered buffer -- [rank][array][level][local column], the collective's layout -- is also written out
+                     in the boundary layout [array][level][column] by a block-copy kernel behind the gather, on the same
+                     stream: a device consumer gets what a single-GPU call would have produced (gathered_device)
 
 `RcclComm` binds librccl.so directly (ctypes: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv) and
 runs on its own HIP stream, which is made to wait for the radiation kernels on the device (rrtmg_hip_stream_wait): the gather
@@ -232,7 +235,12 @@ class ShardedRadiation:
     `ctx` is a climt_amd._lib.Context (device memory) -- or the tests' host emulation, in which case the buffers are numpy.
     """
 
-    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2, allocator=None, force=False):
+    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2, allocator=None, force=False, unpack=False):
+        """unpack=True: on the ranks that hold the gathered outputs they are also put into the BOUNDARY layout -- every array
+        [levels][ncol_total], column fastest, as a single-GPU call would have written it (rrtmg_lw_c_binder.f90:198-202) -- by
+        a block-copy kernel behind the gather on the communicator's stream (rrtmg_hip_copy_blocks): gathered_device(b) /
+        gathered_host(b).  Without it the gathered buffer keeps the collective's layout [rank][array][level][local column]
+        and only gathered_host reassembles it."""
         if gather not in ("all", "root", "none"):
             raise ValueError("gather must be 'all', 'root' or 'none'")
         self.ctx, self.comm, self.gather, self.device = ctx, comm, gather, device
@@ -263,6 +271,75 @@ class ShardedRadiation:
         self.i = 0
         self.inp = None
         self._keep = None
+        self.unpack = bool(unpack) and gathered_here
+        if self.unpack:
+            self._setup_unpack(allocator)
+
+    # ---- boundary layout of the gathered outputs ------------------------------------------------------------------
+    def boundary_offsets(self):
+        """name -> (offset in doubles, levels) of each output array in the unpacked buffer: the arrays one after the other,
+        each [levels][ncol_total]."""
+        off, out = 0, {}
+        for k, lev in zip(self.names, self.levs):
+            out[k] = (off, self.nlay + lev)
+            off += (self.nlay + lev) * self.ncol_total
+        return out
+
+    def unpack_descriptors(self):
+        """One block copy per (rank, array): (src_off, dst_off, rows, cols, src_stride, dst_stride, from_own_flat) in doubles.
+        src: the gathered buffer [rank][array][level][that rank's columns]; with gather='root' rank 0's own block never
+        enters it and is read from its local buffer instead (from_own_flat)."""
+        dst = self.boundary_offsets()
+        out = []
+        for r in range(self.world):
+            rlo, rhi = column_block(self.ncol_total, self.world, r)
+            n_r = rhi - rlo
+            own = self.gather == "root" and r == self.rank
+            for k, (off, rows) in self.offsets(n_r).items():
+                out.append(((0 if own else r * self.block) + off, dst[k][0] + rlo, rows, n_r, n_r, self.ncol_total, own))
+        return out
+
+    def _setup_unpack(self, allocator):
+        total = sum(rows * self.ncol_total for _, rows in self.boundary_offsets().values())
+        desc = self.unpack_descriptors()
+        self._desc = desc
+        if self.device:
+            alloc = allocator or (lambda shape: self._hip.DeviceArray(shape))
+            self.unpacked = [alloc((total,)) for _ in range(self.nbuf)]
+            self._desc_dev = []
+            for own in (False, True):      # two launches at most: blocks read from the gathered buffer / from the own local one
+                rows = [d[:6] for d in desc if d[6] == own]
+                if rows:
+                    arr = np.ascontiguousarray(rows, dtype=np.int64)
+                    self._desc_dev.append((own, self._hip.DeviceArray.from_host(arr), len(rows), max(d[2] for d in rows), max(d[3] for d in rows)))
+        else:
+            self.unpacked = [np.zeros(total) for _ in range(self.nbuf)]
+
+    def _run_unpack(self, b):
+        """Behind the gather of buffer b, in stream order on the communicator's stream (host arrays: at once)."""
+        if not self.device:
+            full, flat, out = self.full[b], self.flat[b], self.unpacked[b]
+            for so, do, rows, cols, ss, ds, own in self._desc:
+                src = flat if own else full
+                for r in range(rows):
+                    out[do + r * ds: do + r * ds + cols] = src[so + r * ss: so + r * ss + cols]
+            return
+        stream = getattr(getattr(self.comm, "stream", None), "s", None)
+        if stream is None:
+            self.comm.wait()       # a communicator without a stream of its own: the gather is complete before the copy starts
+        for own, d, n, mr, mc in self._desc_dev:
+            src = self.flat[b].ptr if own else self.full[b].ptr
+            self.ctx.copy_blocks(d.ptr, n, mr, mc, src, self.unpacked[b].ptr, stream=stream)
+
+    def gathered_device(self, b):
+        """name -> (device pointer, (levels, ncol_total)) of the full-grid outputs of buffer b in the boundary layout
+        (needs unpack=True; valid once the gather of buffer b has completed: finish(), or the buffer's event)."""
+        if not self.unpack:
+            raise RuntimeError("ShardedRadiation(unpack=True) on a rank that holds the gathered outputs is needed for gathered_device")
+        base = self.unpacked[b].ptr if self.device else self.unpacked[b]
+        if self.device:
+            return {k: (base + 8 * off, (rows, self.ncol_total)) for k, (off, rows) in self.boundary_offsets().items()}
+        return {k: (base[off:off + rows * self.ncol_total].reshape(rows, self.ncol_total), (rows, self.ncol_total)) for k, (off, rows) in self.boundary_offsets().items()}
 
     # layout of one rank's block: the arrays one after the other, each [levels][that rank's columns]
     def offsets(self, ncol):
@@ -326,6 +403,8 @@ class ShardedRadiation:
                 self.comm.all_gather(send, recv, self.block)
             else:
                 self.comm.gather_root(send, recv if recv is not None else 0, self.block)
+            if self.unpack:
+                self._run_unpack(b)
             if self.device and not host_wait:
                 self.events[b].record(self.comm.stream.s)
             self.inflight[b] = True
@@ -345,6 +424,14 @@ class ShardedRadiation:
                 self.inflight[b] = False
         self.comm.wait()
 
+    def close(self):
+        """finish() and hand the (shared) context back in the mode it was found in (see DeviceState.close)."""
+        self.finish()
+        prev = getattr(self, "_prev_deferred", None)
+        if self.device and prev is not None:
+            self.ctx.set_deferred(prev)
+            self._prev_deferred = None
+
     def local_host(self, b):
         """This rank's outputs of buffer b as numpy arrays [levels][local columns]."""
         flat = self.flat[b].download() if self.device else self.flat[b]
@@ -356,6 +443,9 @@ class ShardedRadiation:
             return self.local_host(b)
         if self.full[b] is None:
             return None
+        if self.unpack:        # already in the boundary layout (on the device: one download, no host reassembly)
+            flat = self.unpacked[b].download() if self.device else self.unpacked[b]
+            return {k: flat[off:off + rows * self.ncol_total].reshape(rows, self.ncol_total).copy() for k, (off, rows) in self.boundary_offsets().items()}
         full = self.full[b].download() if self.device else self.full[b]
         mine = self.local_host(b)
         cols = {k: [] for k in self.names}

@@ -262,4 +262,16 @@ def live_oracle(c, mcica, chunk=128, procs=None):
         parts = pool.map(_live_oracle_worker, jobs)
     sw = {k: np.concatenate([p[0][k] for p in parts], axis=1) for k, _ in SW_OUT}
     lw = {k: np.concatenate([p[1][k] for p in parts], axis=1) for k, _ in LW_OUT}
+    require_reference_oracle(parts[0][2])
+    assert all(p[2] == parts[0][2] for p in parts)
     return sw, lw, parts[0][2]
+
+
+def require_reference_oracle(kind):
+    """The live oracle of the GPU tests is the reference Fortran itself (oracle/_ref, built in the container and shipped to
+    the GPU box with the snapshot).  If the libraries did not travel the tests would silently fall back to the C restatement:
+    that must be somebody's decision (RRTMG_TEST_ALLOW_PORT_ORACLE=1), not an accident."""
+    if os.environ.get("RRTMG_TEST_ALLOW_PORT_ORACLE", "") in ("", "0"):
+        assert kind == "reference", ("oracle/_ref/librrtmg_{sw,lw}_ref.so are not here: the live oracle would be the C restatement "
+                                     "(oracle/), not the reference Fortran.  Build them (oracle/build_ref.sh) or set "
+                                     "RRTMG_TEST_ALLOW_PORT_ORACLE=1 to compare with the restatement knowingly.")

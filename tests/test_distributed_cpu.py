@@ -48,6 +48,15 @@ def _worker(rank, world, port, q):
             b = sr.step(mcica=mcica)
         sr.finish()
         res["sr_" + mode] = (sr.gathered_host(b), (sr.lo, sr.hi))
+    # ... and with the boundary-layout unpack behind the gather (the descriptors the device kernel gets, run by numpy here)
+    for mode in ("all", "root"):
+        sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, nlay, gather=mode, device=False, unpack=True)
+        sr.set_inputs(c)
+        for _ in range(3):
+            b = sr.step(mcica=mcica)
+        sr.finish()
+        dev = {k: v[0].copy() for k, v in sr.gathered_device(b).items()} if sr.unpack else None
+        res["un_" + mode] = (sr.gathered_host(b), dev, sr.unpack_descriptors())
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res))
@@ -89,6 +98,15 @@ def test_two_rank_sharding_is_bit_identical():
             assert all(np.array_equal(got[k], full[k]) for k in full)
         else:
             assert got is None
+        # unpacked: every array [levels][all columns], on every rank that holds the gather
+        for mode in ("all", "root"):
+            got, dev, desc = res[rank]["un_" + mode]
+            if mode == "root" and rank != 0:
+                assert got is None and dev is None
+                continue
+            assert all(np.array_equal(got[k], full[k]) and np.array_equal(dev[k], full[k]) for k in full), (rank, mode)
+            assert len(desc) == 2 * len(full) and sum(d[2] * d[3] for d in desc) == sum(v.size for v in full.values())
+            assert [d[6] for d in desc].count(True) == (len(full) if mode == "root" else 0)      # root: own block from the local buffer
 
 
 def test_mersenne_twister_shards_differ_without_the_skip_ahead():

@@ -187,7 +187,9 @@ def test_against_live_oracle_at_larger_size(gpu_ctx, ncol, nlay):
         esw = {k: np.concatenate([p[k] for p in parts_sw], axis=1) for k in ("swuflx", "swdflx", "swhr", "swuflxc", "swdflxc", "swhrc")}
         elw = {k: np.concatenate([p[k] for p in parts_lw], axis=1) for k in ("uflx", "dflx", "hr", "uflxc", "dflxc", "hrc")}
     else:
+        from helpers import require_reference_oracle
         from oracle.port_driver import PortLW, PortSW
+        require_reference_oracle("port")
         esw, elw = PortSW().fluxes(c, mcica=True), PortLW().fluxes(c, mcica=True)
     _check(gpu_ctx.sw_fluxes(c, mcica=True), esw)
     _check(gpu_ctx.lw_fluxes(c, mcica=True), elw)
@@ -458,6 +460,29 @@ def test_components_on_gpu_reproduce_reference_caches():
             climt_amd.RRTMGLongwave()
         else:
             raise RuntimeError("SYNTHETIC (real tables: nothing to refuse)")
+
+
+def test_longwave_cache_comparisons_execute_on_an_ingested_blob(tmp_path, monkeypatch):
+    """What happens the day the real longwave data file has been ingested (tools/ingest_lw_data.sh), on the GPU: a table blob
+    whose lw/meta/synthetic flag is clear -- byte for byte what the ingestion chain packs from a data file holding today's raw
+    tables (tests/test_lw_ingest.py::test_ingest_chain_reproduces_the_shipped_blob) -- makes RRTMGLongwave() construct without
+    allow_synthetic_tables and puts the reference's four longwave cache classes under its own criterion, 1e-8.  The stand-in
+    data cannot reproduce physical values: the assertion is that every comparison RAN (with the real file: failed == 0)."""
+    import climt_amd
+    from climt_amd.rrtmg import common
+    from test_lw_ingest import blob_with_flag, compare_lw_caches
+    monkeypatch.delenv("RRTMG_HIP_ALLOW_SYNTHETIC_LW", raising=False)
+    with pytest.raises(RuntimeError, match="SYNTHETIC"):
+        climt_amd.RRTMGLongwave()
+    monkeypatch.setenv("RRTMG_HIP_LW_DATA", blob_with_flag(str(tmp_path / "ingested.bin"), 0))
+    try:
+        ran, failed = compare_lw_caches(lambda **kw: climt_amd.RRTMGLongwave(**kw))
+        assert not common.make_context(0).lw_tables_synthetic()
+    finally:
+        monkeypatch.delenv("RRTMG_HIP_LW_DATA")
+        monkeypatch.setenv("RRTMG_HIP_ALLOW_SYNTHETIC_LW", "1")
+        climt_amd.RRTMGLongwave()              # the shared context goes back to the shipped table file
+    assert ran >= 4 * 7 and failed > 0, (ran, failed)
 
 
 def test_component_outputs_are_recycled_only_when_dropped():
@@ -837,6 +862,60 @@ def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
         sr.finish()
         got = sr.gathered_host(b)
         assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+        sr.close()
+        if mode != "none":
+            # the gathered outputs in the BOUNDARY layout on the device: the block-copy kernel behind the gather, same stream
+            from climt_amd import _hip
+            sr = ShardedRadiation(gpu_ctx, comm, N, L, gather=mode, force=True, unpack=True)
+            sr.set_inputs(c)
+            for i in range(3):
+                b = sr.step(mcica=True, sync=False)
+            sr.finish()
+            for k, (ptr, shape) in sr.gathered_device(b).items():
+                host = np.empty(shape)
+                _hip._ck(_hip.lib().hipMemcpy(C.c_void_p(host.ctypes.data), C.c_void_p(ptr), C.c_size_t(host.nbytes), C.c_int(2)), "D2H")
+                assert np.array_equal(host, want[k]), k
+            assert all(np.array_equal(v, want[k]) for k, v in sr.gathered_host(b).items())
+            sr.close()
     finally:
         gpu_ctx.set_deferred(False)
         comm.close()
+
+
+def test_copy_blocks_kernel_unpacks_a_three_rank_gather(gpu_ctx):
+    """rrtmg_hip_copy_blocks with the descriptors ShardedRadiation builds for THREE ranks with unequal blocks (1000 columns:
+    334 + 333 + 333), on a gathered buffer assembled on the host: [rank][array][level][local column] ->
+    [array][level][column], against numpy.  (One GPU: the collective itself is covered by the one-rank RCCL test and the
+    two-rank gloo test; this is the multi-rank layout arithmetic on the device.)"""
+    from climt_amd import _hip
+    from climt_amd.distributed import ShardedRadiation, column_block
+
+    class FakeComm:
+        rank, world, kind, stream = 1, 3, "none", None
+    N, L = 1000, 7
+    for mode in ("all", "root"):
+        FakeComm.rank = 1 if mode == "all" else 0
+        sr = ShardedRadiation(None, FakeComm(), N, L, gather=mode, device=False, unpack=True, idrv=True)
+        rng = np.random.default_rng(5)
+        full = {k: rng.standard_normal((L + lev, N)) for k, lev in zip(sr.names, sr.levs)}
+        gathered = np.zeros(sr.block * 3)
+        own = np.zeros(sr.block)
+        for r in range(3):
+            lo, hi = column_block(N, 3, r)
+            for k, (off, rows) in sr.offsets(hi - lo).items():
+                dst = own if (mode == "root" and r == sr.rank) else gathered[r * sr.block:]
+                dst[off:off + rows * (hi - lo)] = full[k][:, lo:hi].ravel()
+        desc = sr.unpack_descriptors()
+        total = sum(rows * N for _, rows in sr.boundary_offsets().values())
+        out = _hip.DeviceArray((total,))
+        g_dev, o_dev = _hip.DeviceArray.from_host(gathered), _hip.DeviceArray.from_host(own)
+        for from_own in (False, True):
+            rows = [d[:6] for d in desc if d[6] == from_own]
+            if not rows:
+                continue
+            d_dev = _hip.DeviceArray.from_host(np.ascontiguousarray(rows, dtype=np.int64))
+            gpu_ctx.copy_blocks(d_dev.ptr, len(rows), max(d[2] for d in rows), max(d[3] for d in rows), (o_dev if from_own else g_dev).ptr, out.ptr)
+        _hip.synchronize()
+        flat = out.download()
+        for k, (off, rows) in sr.boundary_offsets().items():
+            assert np.array_equal(flat[off:off + rows * N].reshape(rows, N), full[k]), (mode, k)

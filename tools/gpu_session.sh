@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun session (development tool): tools/gpu_session.sh <tag> <sections...>
-#   sections: tests bench dist sizes ab:<lib1,lib2,...> prof pmc pmclarge sq
+#   sections: tests smoke bench dist sizes ab:<lib1,lib2,...> phases prof pmc pmclarge sq
 # Everything lands under gpurun_out/<tag>_*; the summaries to be judged are copied into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 export RRTMG_HIP_ALLOW_SYNTHETIC_LW=1
@@ -8,7 +8,7 @@ R=$1; shift
 O=gpurun_out
 mkdir -p $O
 stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py $f > $2; rm -rf $1; }   # (the raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
-pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f _solve_ > $2; rm -rf $1; }
+pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f rrtmg:: > $2; rm -rf $1; }
 for sec in "$@"; do
   echo "=== section $sec ($(date +%T))"
   case $sec in
@@ -42,6 +42,11 @@ except Exception as e:
     print('$lib $mode FAILED', e)" | tee -a $O/${R}_ab.txt
         done
       done ;;
+    phases)
+      # the diagnostic build with phase timers in the longwave sweeps (climt_amd/_lib/lib_phases.so: -DRRTMG_LW_PHASES)
+      for mode in "" "--cloudy"; do
+        RRTMG_HIP_LIB=$PWD/climt_amd/_lib/lib_phases.so timeout 200 python bench.py --no-cpu-baseline --no-extra --serial --steps 2 --warmup 1 --min-seconds 0 $mode 2>&1 | grep -A1 "lw phases" | tail -2 | tee -a $O/${R}_lw_phases.txt
+      done ;;
     prof)
       for mode in clear cloudy; do
         flag=""; [ $mode = cloudy ] && flag="--cloudy"
@@ -59,7 +64,7 @@ except Exception as e:
         flag=""; [ $mode = cloudy ] && flag="--cloudy"
         for c in FETCH_SIZE WRITE_SIZE; do
           out=$O/pmc_${mode}_$c$tag; rm -rf $out
-          timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out -- python bench.py --columns $n --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 $flag > $out.log 2>&1
+          timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out -- python bench.py --columns $n --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
           pmc $out $O/${R}_pmc_${mode}_$c$tag.txt; cat $O/${R}_pmc_${mode}_$c$tag.txt
         done
       done ;;
@@ -69,7 +74,7 @@ except Exception as e:
         i=0
         for P in "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
           i=$((i+1)); out=$O/sq_${mode}_$i; rm -rf $out
-          timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 $flag > $out.log 2>&1
+          timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
           pmc $out $O/${R}_sq_${mode}_$i.txt
         done
         cat $O/${R}_sq_${mode}_1.txt $O/${R}_sq_${mode}_2.txt > $O/${R}_pmc_${mode}_sq.txt

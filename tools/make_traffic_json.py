@@ -10,26 +10,34 @@
   flops    = (2 x FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions x 64 lanes per launch.
 Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 columns the value is per
 launch of one 32768-column chunk.
-usage: tools/make_traffic_json.py [round=r02]"""
+  "step|<columns>|<levels>|<clear|cloudy>" = the same counters summed over EVERY kernel of one LW+SW step (preparation,
+             cloud optics / sub-column masks, both solve variants, flux + heating): sum over kernels of (average per dispatch x
+             dispatches) / steps, steps = dispatches of sw_prep_fused_kernel (one per step); "step_kernels|..." lists the terms.
+usage: tools/make_traffic_json.py [round=r03]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 
 
-def get(fn, counter):
+def get_all(fn, counter):
+    """kernel -> (average per dispatch, dispatches) for every kernel in the file"""
     out = {}
     path = os.path.join(ROOT, "profiles", fn)
     if not os.path.exists(path):
         return out
     for line in open(path):
-        m = re.match(r"(.*?)\s+%s\s+dispatches\s+\d+\s+avg\s+(\S+)" % counter, line.strip())
-        if m and "_solve_" in m.group(1):
-            out[m.group(1).strip()] = float(m.group(2))
+        m = re.match(r"(.*?)\s+%s\s+dispatches\s+(\d+)\s+avg\s+(\S+)" % counter, line.strip())
+        if m:
+            out[m.group(1).strip()] = (float(m.group(3)), int(m.group(2)))
     return out
+
+
+def get(fn, counter):
+    return {k: v[0] for k, v in get_all(fn, counter).items() if "_solve_" in k}
 
 
 traffic = {"_doc": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s_pmc_*; see tools/make_traffic_json.py" % rnd}
@@ -41,6 +49,12 @@ for mode in ("clear", "cloudy"):
             b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
             if b > 1.0e6:
                 traffic["%s|%d|60|%s" % (k, ncol, mode)] = b
+        fa, wa = get_all("%s_pmc_%s_FETCH_SIZE%s.txt" % (rnd, mode, tag), "FETCH_SIZE"), get_all("%s_pmc_%s_WRITE_SIZE%s.txt" % (rnd, mode, tag), "WRITE_SIZE")
+        steps = fa.get("rrtmg::sw_prep_fused_kernel", (0, 0))[1]
+        if steps and len(fa) > 4:      # (a pass that recorded every kernel, not only the solve kernels)
+            terms = {k: (2.0 * fa[k][0] * fa[k][1] + wa.get(k, (0.0, 0))[0] * wa.get(k, (0.0, 0))[1]) * 1024.0 / steps for k in fa}
+            traffic["step|%d|60|%s" % (ncol, mode)] = sum(terms.values())
+            traffic["step_kernels|%d|60|%s" % (ncol, mode)] = {k: v for k, v in sorted(terms.items(), key=lambda kv: -kv[1]) if v > 1.0e5}
     sq = {c: get("%s_pmc_%s_sq.txt" % (rnd, mode), c) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")}
     for k in sq["SQ_INSTS_VALU_FMA_F64"]:
         f = 64.0 * (2.0 * sq["SQ_INSTS_VALU_FMA_F64"][k] + sq["SQ_INSTS_VALU_MUL_F64"].get(k, 0) + sq["SQ_INSTS_VALU_ADD_F64"].get(k, 0) + sq["SQ_INSTS_VALU_TRANS_F64"].get(k, 0))
