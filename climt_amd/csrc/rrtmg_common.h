@@ -4,15 +4,12 @@
 
 #include <cstdint>
 
-// Build-time experiment switches (never set in the product build; `RRTMG_HIP_BUILD_FLAGS=-D... python climt_amd/build.py`
-// builds a variant library that tools/ab*.sh time next to the product one -- results of RRTMG_ABL_* builds are WRONG
-// by design, they only answer "what does this part cost"): RRTMG_ABL_NOSCRATCH (sweep state to one row),
-// RRTMG_ABL_UNIFORMK (k-table rows collapsed), RRTMG_ABL_SCALARK (k-table rows of lane 0 through the scalar cache: what
-// the per-lane gathers cost), RRTMG_ABL_UNIFORMLOOKUP / NOTAUG / NOPLANCK (LW), RRTMG_ABL_NORECOMPUTE (SW second-sweep
-// optics); RRTMG_EXACT_DIV / RRTMG_EXACT_SQRT / RRTMG_EXACT_REFTRA (IEEE divide / square root, the reference's quotient order in reftra), RRTMG_SW_NOLDS / RRTMG_LW_NOLDS (tables left in global
-// memory), RRTMG_SW_KLDS / RRTMG_SWC_EXPLDS (what the shortwave kernels stage in LDS), RRTMG_{SW,LW}_WAVES /
-// RRTMG_{SW,SWC,LW}_WGWAVES / RRTMG_SWC_WAVES / RRTMG_LW_GMAX / RRTMG_LW_KU / RRTMG_LW_TILEGROUP (occupancy, work-item and launch shape), RRTMG_LW_QDIV (quick division in the
-// longwave table index).
+#include "rrtmg_profile.h"
+
+// One code path: the experiments of rounds 1-3 (ablations, occupancy and launch-shape variants, alternative layouts) were
+// build switches; their results are in DESIGN.md 5 and the git history, the switches are gone.  The only conditional
+// compilation left separates the host emulation of the device functions (tests/emu: no __HIP_DEVICE_COMPILE__) from the
+// device build, and RRTMG_PROFILE (rrtmg_profile.h) adds timing diagnostics to a non-product build.
 #define RRTMG_HD __host__ __device__ __forceinline__
 #define RRTMG_WAVE 64
 
@@ -37,19 +34,13 @@ RRTMG_HD void report_error(int *flag, int code) {
 // Quick fp64 division for the flux arithmetic of the shortwave hot loops: v_rcp_f64 + ONE Newton-Raphson step
 // (relative error <= 2.2e-15, i.e. ~20 ulp; 4 instructions) instead of the 11-instruction IEEE sequence (div_scale x2,
 // rcp, 6 fma, div_fmas, div_fixup) -- divisions were ~60 % of the VALU instructions of the solve kernels, which are
-// VALU-issue bound.  Fluxes move by ~1e-10 W m-2 (bar: 1e-2).  RRTMG_QDIV_NR=2 gives 1 ulp.  Operands here are
+// VALU-issue bound.  Fluxes move by ~1e-10 W m-2 (bar: 1e-2); a second step would give 1 ulp.  Operands here are
 // O(1e-20..1e20) and never zero/inf/denormal.  NOT used where an integer selects a table ROW (specparm -> js):
 // those keep the correctly rounded `/`.  On the host (tests/emu) it is the plain division.
-#ifndef RRTMG_QDIV_NR
-#define RRTMG_QDIV_NR 1
-#endif
 RRTMG_HD double qdiv(double a, double b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRTMG_EXACT_DIV)
+#if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(b);                    // measured on gfx950: relative error <= 4.6e-8
   r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);    // one Newton step: <= 2.2e-15 (tools/micro/rcp_accuracy.hip)
-#if RRTMG_QDIV_NR >= 2
-  r = __builtin_fma(__builtin_fma(-b, r, 1.0), r, r);    // two: 1 ulp
-#endif
   return a * r;
 #else
   return a / b;
@@ -60,7 +51,7 @@ RRTMG_HD double qrcp(double b) { return qdiv(1.0, b); }
 // coupled Goldschmidt iteration and one residual correction -- 8 instructions instead of the 18 of the IEEE expansion
 // (range scaling, class fix-up, second correction).  Measured <= 1 ulp (tools/micro/rsq_accuracy.hip).
 RRTMG_HD double qsqrt(double a) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRTMG_EXACT_SQRT)
+#if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(a);
   double g = a * y, h = 0.5 * y;
   const double r = __builtin_fma(-h, g, 0.5);
@@ -123,29 +114,18 @@ template <int G> RRTMG_HD void vstore(double *p, const V<G> &x) {
 }
 
 // Scratch-slab rows of the solve kernels: the G values of one (layer, field) for the 64 lanes of a tile.
-// RRTMG_SCR_PAIRMAJOR = 0: [lane][G] (a lane's G values contiguous: two 16-byte accesses 32 bytes apart for G = 4);
-// 1: [G/2][lane][2] (each 16-byte access of the wave is one contiguous 1 KB run).  p -> this lane's first element
-// (slab row + lane * G, resp. lane * 2), stride = lanes per row.  RRTMG_SCR_NT: non-temporal accesses (the slab is written
-// once and read once, a whole sweep later).
-#ifndef RRTMG_SCR_PAIRMAJOR
-#define RRTMG_SCR_PAIRMAJOR 1
-#endif
-#ifndef RRTMG_SCR_NT
-#define RRTMG_SCR_NT 1
-#endif
-template <int G> RRTMG_HD long scr_lane_offset(int lane) { return (RRTMG_SCR_PAIRMAJOR && G % 2 == 0) ? (long)lane * 2 : (long)lane * G; }
+// Pair-major, [G/2][lane][2]: each 16-byte access of the wave is one contiguous 1 KB run (round 1: [lane][G], 16 bytes every
+// 32 per instruction).  p -> this lane's first element (slab row + lane * 2), stride = lanes per row.  Non-temporal
+// accesses: the slab is written once and read once, a whole sweep later.
+template <int G> RRTMG_HD long scr_lane_offset(int lane) { return (G % 2 == 0) ? (long)lane * 2 : (long)lane * G; }
 template <int G> RRTMG_HD V<G> scr_load(const double *p, long stride) {
   V<G> r;
   if constexpr (G % 2 == 0) {
     _Pragma("unroll") for (int i = 0; i < G; i += 2) {
-      const double *q = p + (RRTMG_SCR_PAIRMAJOR ? (long)(i / 2) * stride * 2 : (long)i);
+      const double *q = p + (long)(i / 2) * stride * 2;
 #if defined(__HIP_DEVICE_COMPILE__)
       typedef double d2 __attribute__((ext_vector_type(2)));
-#if RRTMG_SCR_NT
       const d2 x = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(q));
-#else
-      const d2 x = *reinterpret_cast<const d2 *>(q);
-#endif
       r.v[i] = x.x; r.v[i + 1] = x.y;
 #else
       r.v[i] = q[0]; r.v[i + 1] = q[1];
@@ -159,15 +139,11 @@ template <int G> RRTMG_HD V<G> scr_load(const double *p, long stride) {
 template <int G> RRTMG_HD void scr_store(double *p, long stride, const V<G> &x) {
   if constexpr (G % 2 == 0) {
     _Pragma("unroll") for (int i = 0; i < G; i += 2) {
-      double *q = p + (RRTMG_SCR_PAIRMAJOR ? (long)(i / 2) * stride * 2 : (long)i);
+      double *q = p + (long)(i / 2) * stride * 2;
 #if defined(__HIP_DEVICE_COMPILE__)
       typedef double d2 __attribute__((ext_vector_type(2)));
       d2 v; v.x = x.v[i]; v.y = x.v[i + 1];
-#if RRTMG_SCR_NT
       __builtin_nontemporal_store(v, reinterpret_cast<d2 *>(q));
-#else
-      *reinterpret_cast<d2 *>(q) = v;
-#endif
 #else
       q[0] = x.v[i]; q[1] = x.v[i + 1];
 #endif
@@ -177,19 +153,16 @@ template <int G> RRTMG_HD void scr_store(double *p, long stride, const V<G> &x) 
   }
 }
 
-// Partial-flux planes: written once by a solve kernel, read once by the flux kernel.  RRTMG_PART_NT: non-temporal accesses.
-#ifndef RRTMG_PART_NT
-#define RRTMG_PART_NT 1
-#endif
+// Partial-flux planes: written once by a solve kernel, read once by the flux kernel: non-temporal accesses.
 RRTMG_HD void part_store(double *p, double v) {
-#if defined(__HIP_DEVICE_COMPILE__) && RRTMG_PART_NT
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_nontemporal_store(v, p);
 #else
   *p = v;
 #endif
 }
 RRTMG_HD double part_load(const double *p) {
-#if defined(__HIP_DEVICE_COMPILE__) && RRTMG_PART_NT
+#if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_nontemporal_load(p);
 #else
   return *p;
@@ -199,19 +172,7 @@ RRTMG_HD double part_load(const double *p) {
 // g-point-fastest table view: element (row, ig0 + j) at p[row * NG + j], p already offset by the first g-point
 template <int G, int NG> struct KTab {
   const double *p;
-#ifdef RRTMG_ABL_UNIFORMK
-  RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)(row & 1) * NG); }
-#elif defined(RRTMG_ABL_SCALARK) && defined(__HIP_DEVICE_COMPILE__)
-  RRTMG_HD V<G> operator[](int row) const {   // rows through the scalar cache
-    typedef const __attribute__((address_space(4))) double *cptr;
-    cptr q = (cptr)(p + (long)__builtin_amdgcn_readfirstlane(row) * NG);
-    V<G> r;
-    _Pragma("unroll") for (int i = 0; i < G; ++i) r.v[i] = q[i];
-    return r;
-  }
-#else
   RRTMG_HD V<G> operator[](int row) const { return vload<G>(p + (long)row * NG); }
-#endif
 };
 
 // bit l of a 4-word (<= 256 layers) cloud mask held in registers: selects instead of dynamic indexing, which

@@ -3,15 +3,13 @@
 // Launch sequence of one rrtmg_hip_lw_fluxes call (all on the context's longwave stream):
 //   lw_prep_fused_kernel <<<tiles, 16 waves>>>  inatm + setcoef per (column, layer), then the column part (laytrop, precipitable
 //                        water -> secdiff, tile cloud flag) on what the layer part left in LDS; non-McICA cloudy tiles: cldprop
-//                        and the rtrnmr overlap factors         (RRTMG_HIP_UNFUSED=1: lw_prep_layer_kernel, lw_prep_kernel,
-//                        lw_cloud_kernel, lw_mr_kernel as separate launches)
+//                        and the rtrnmr overlap factors
 //   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
 //   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles):
 //     lw_solve_all_kernel  one launch per variant (cloud-free / cloudy tiles): wavefront = tile(64 columns) x work item (4|2
 //                          g-points of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
 //     lw_fluxheat_kernel   <<<(tiles, levels/15), 16 waves>>>  band / g-point integration per interface + heating rates
-//                          (RRTMG_HIP_UNFUSED=2: lw_flux_kernel + lw_heat_kernel)
 #include "rrtmg_ctx.h"
 #include "rrtmg_lw_device.h"
 #include "rrtmg_lw_host.h"
@@ -19,28 +17,11 @@
 
 namespace rrtmg {
 
-__global__ void __launch_bounds__(64) lw_prep_layer_kernel(LwDev d, LwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_prep_layer(d, T, col, blockIdx.y);
-}
-__global__ void __launch_bounds__(64) lw_prep_kernel(LwDev d, LwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_prep_column(d, T, col);
-  // tile flag: does any column of this 64-column tile have a cloud? (selects the solve kernel variant)
-  bool cld = false;
-  if (col < d.ncol && d.icld >= 1 && d.cldfr)
-    for (int l = 0; l < d.nlay; ++l) cld = cld || d.cldfr[(long)l * d.ncol + col] > 0.0;
-  const unsigned long long any = __ballot(cld);
-  if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
-}
 // Preparation in ONE launch (see sw_prep_fused_kernel): phase 1 the layer part, layers strided over the 16 waves; phase 2
 // wave 0: the column scan (laytrop, precipitable water -> diffusivity angles) on the rows just written, and the tile's
 // cloud flag; phase 3, cloudy tiles only: cldprop / the rtrnmr overlap factors (one wave each, sequential in the layers as
 // the reference); with McICA the cldprmc band optics stay a launch of their own (see sw_prep_fused_kernel).
-#ifndef RRTMG_PREP_WAVES
-#define RRTMG_PREP_WAVES 16
-#endif
-constexpr int kPrepWaves = RRTMG_PREP_WAVES;
+constexpr int kPrepWaves = 16;
 __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
@@ -48,6 +29,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
   // what the column scan reads back from the layer part -- [layer][coldry | h2o | lower flag][lane] -- and the per-wave cloud
   // flags, in LDS (grids of up to kKeepLayers layers; deeper ones re-read the slab)
   constexpr int kKeepLayers = 104;
+  static_assert(kKeepLayers * 3 * 64 * sizeof(double) + 1024 <= 160 * 1024, "lw_prep_fused_kernel: LDS budget of gfx950 (160 KB per workgroup)");
   __shared__ double sh_keep[kKeepLayers * 3 * 64];
   __shared__ int sh_any[kPrepWaves];
   const bool keep = d.nlay <= kKeepLayers;
@@ -77,15 +59,6 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
   if (w == kPrepWaves - 1 && maxrand) lw_mr_column(d, col);
 }
 
-__global__ void __launch_bounds__(64) lw_cloud_kernel(LwDev d, LwTab T) {
-  if (!d.tile_cld[blockIdx.x]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_cloud_column(d, T, col);
-}
-__global__ void __launch_bounds__(64) lw_mr_kernel(LwDev d) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_mr_column(d, col);
-}
 __global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T) {
   if (!d.tile_cld[blockIdx.x]) return;
   const int col = blockIdx.x * 64 + threadIdx.x;
@@ -105,27 +78,18 @@ __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
 // k-distribution slice in LDS: columns ig0..ig0+G-1 of the band's table slab, [nrows][G], <= 66 KB, two workgroups per
 // CU.  Every absorption-coefficient / Planck-fraction row a lane needs is then a 16/32-byte LDS read at a per-lane
 // row (bank conflicts only) instead of a per-lane gather through the vector L1, whose return path (64 B/clk/CU) the
-// ~30 row gathers per layer saturated: with the rows through the scalar cache (RRTMG_ABL_SCALARK) the kernel ran 23 %
+// ~30 row gathers per layer saturated: with the rows through the scalar cache (an ablation) the kernel ran 23 %
 // faster, which bounded what staging could win.
 // Launch order: tile groups of kLwTileGroup, within a group items heaviest first (LwTab::sched), tile blocks fastest
 // -- the group's prep rows stay L2-resident while its items run.  Speed only, never correctness.
-#ifndef RRTMG_LW_WAVES
-#define RRTMG_LW_WAVES 2
-#endif
-#ifndef RRTMG_LW_WGWAVES
-#define RRTMG_LW_WGWAVES 4
-#endif
-constexpr int kLwWgWaves = RRTMG_LW_WGWAVES;
-#ifndef RRTMG_LW_TILEGROUP
-#define RRTMG_LW_TILEGROUP 32
-#endif
-constexpr int kLwTileGroup = RRTMG_LW_TILEGROUP;
+constexpr int kLwWgWaves = 4;
+constexpr int kLwTileGroup = 32;
 constexpr int kLwGroupBlocks = kLwTileGroup / kLwWgWaves;
 static_assert(kLwTileGroup % kLwWgWaves == 0, "tile group must be a whole number of workgroups");
 // Two variants are launched back to back (see sw_solve_all_kernel): CLD = false for the cloud-free tiles.
 // MR = true: non-McICA maximum/random overlap (rtrnmr).
 template <bool CLD, bool MR>
-__global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
+__global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(2))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int q = blockIdx.x;
   const int per = kLwGroupBlocks * T.nitem;
   const int grp = q / per, r = q % per;
@@ -138,77 +102,30 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
       if (ctile0 + w < ntile && (d.tile_cld[tile0 + ctile0 + w] != 0) == CLD) mine = true;
     if (!mine) return;
   }
-  if (d.only_item >= 0 && k != d.only_item) return;
+  RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int slot = T.sched[k], item = T.item[slot];
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
-#ifdef RRTMG_LW_NOLDS
-  constexpr bool kLdsK = false;
-  const double *sh_k = nullptr;
-#else
   constexpr bool kLdsK = true;
-  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * RRTMG_LW_GMAX];   // rows are read 16 bytes at a time
+  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * 4];   // rows are read 16 bytes at a time
   {
     const LwBandTab &B = T.b[item & 0xff];
     const double *src = T.t + B.slab + ig0;
-    const int ng = B.ng, sh = g == 8 ? 3 : g == 4 ? 2 : 1, n = B.nrows << sh;
+    const int ng = B.ng, sh = g == 4 ? 2 : 1, n = B.nrows << sh;
     for (int i = threadIdx.x; i < n; i += 64 * kLwWgWaves) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
   }
   __syncthreads();
-#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ctile = ctile0 + wave, tile = tile0 + ctile;
   if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * g);
+  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + lane * 2;
   LwPartSink sink = lw_part_sink(d, slot, col);
   lw_solve_item<CLD, MR, kLdsK>(d, T, item, col, scr, 64, sink, sh_k);
 }
 
-#ifdef RRTMG_LW_MERGED
-// Experiment: BOTH variants in one launch -- every wavefront takes the clear-sky or the cloudy code by its own tile's flag
-// (wave-uniform), so cloud-free and cloudy tiles of a grid run side by side instead of one launch after the other, and a grid
-// with only one kind of tile does not pay for a launch that finds nothing to do.
-template <bool MR>
-__global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_LW_WAVES))) lw_solve_merged_kernel(LwDev d, LwTab T, int tile0, int ntile) {
-  const int q = blockIdx.x;
-  const int per = kLwGroupBlocks * T.nitem;
-  const int grp = q / per, r = q % per;
-  const int k = r / kLwGroupBlocks;
-  const int ctile0 = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;
-  if (ctile0 >= ntile) return;
-  const int slot = T.sched[k], item = T.item[slot];
-  const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
-  __shared__ __attribute__((aligned(16))) double sh_k[kLwSlabMaxRows * RRTMG_LW_GMAX];
-  {
-    const LwBandTab &B = T.b[item & 0xff];
-    const double *src = T.t + B.slab + ig0;
-    const int ng = B.ng, sh = g == 8 ? 3 : g == 4 ? 2 : 1, n = B.nrows << sh;
-    for (int i = threadIdx.x; i < n; i += 64 * kLwWgWaves) sh_k[i] = src[(long)(i >> sh) * ng + (i & (g - 1))];
-  }
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = ctile0 + wave, tile = tile0 + ctile;
-  if (ctile >= ntile) return;
-  const int lane = threadIdx.x & 63;
-  const int col = tile * 64 + lane;
-  if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kLwNGpt + ((item >> 20) & 0xff)) * (long)LF_N * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * g);
-  LwPartSink sink = lw_part_sink(d, slot, col);
-  if (__builtin_amdgcn_readfirstlane(d.tile_cld[tile]) != 0) lw_solve_item<true, MR, true>(d, T, item, col, scr, 64, sink, sh_k);
-  else lw_solve_item<false, false, true>(d, T, item, col, scr, 64, sink, sh_k);
-}
-#endif
 
-__global__ void __launch_bounds__(64) lw_flux_kernel(LwDev d, LwTab T, int tile0) {
-  const int col = (tile0 + blockIdx.x) * 64 + threadIdx.x;
-  if (col < d.ncol) lw_flux_level(d, T, col, blockIdx.y, T.nitem, d.tile_cld[tile0 + blockIdx.x] != 0);
-}
-__global__ void __launch_bounds__(64) lw_heat_kernel(LwDev d, LwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) lw_heat_layer(d, T, col, blockIdx.y);
-}
 // band integration AND heating rates in one launch (see sw_fluxheat_kernel)
 constexpr int kFluxLev = 15;   // 16 waves per workgroup: the halo level is 1 in 16 of the partial-plane reads
 __global__ void __launch_bounds__(64 * (kFluxLev + 1)) lw_fluxheat_kernel(LwDev d, LwTab T, int tile0) {
@@ -280,8 +197,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.idrv = a->idrv ? 1 : 0;
   d.inflag = a->inflglw; d.iceflag = a->iceflglw; d.liqflag = a->liqflglw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
-  d.only_item = -1;
-  if (const char *e = getenv("RRTMG_HIP_ONLY_ITEM")) d.only_item = atoi(e);
+  RRTMG_PROFILE_READ_ONLY_ITEM(d)
   d.fluxfac = (2.0 * asin(1.0)) * 2.e4;       // rrtmg_lw_rad.nomcica.f90:420-421
   const bool maxrand = !d.mcica && d.icld >= 2;   // rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544)
   if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
@@ -346,7 +262,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     if (d.idrv) { d.duflx_dt = wd("o.du", nl1); d.duflxc_dt = wd("o.duc", nl1); }
   }
   if (!ok) return ctx->status;
-#ifdef RRTMG_LW_PHASES
+#ifdef RRTMG_PROFILE
   d.phase = (unsigned long long *)ctx->buf("lw.w.phase", 16 * 8);
   if (!d.phase) return ctx->status;
   RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.phase, 0, 16 * 8, s));
@@ -368,22 +284,9 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     launch_interface_values(s, N, L, d.tlay, d.tsfc, d.play, d.plev, tl);
     d.tlev = tl;
   }
-  // RRTMG_HIP_UNFUSED (A/B; same results): bit 0 = separate preparation kernels, bit 1 = separate flux and heating-rate kernels
-  static const int unfused_bits = getenv("RRTMG_HIP_UNFUSED") ? atoi(getenv("RRTMG_HIP_UNFUSED")) : 0;
-  const bool unfused = unfused_bits & 1, unfused_flux = unfused_bits & 2;
-  if (unfused) {
-    hipLaunchKernelGGL(lw_prep_layer_kernel, dim3(ntile, L), blk, 0, s, d, T);
-    hipLaunchKernelGGL(lw_prep_kernel, gcol, blk, 0, s, d, T);
-  } else {
-    hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0);
-  }
+  hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0);
   if (clouds) {
-    if (!d.mcica) {
-      if (unfused) {
-        hipLaunchKernelGGL(lw_cloud_kernel, gcol, blk, 0, s, d, T);
-        if (maxrand) hipLaunchKernelGGL(lw_mr_kernel, gcol, blk, 0, s, d);
-      }
-    } else {
+    if (d.mcica) {
       hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);
       if (a->cldfmcl) {
         const double *cm = in(a->cldfmcl, nl * kLwNGpt, "cldfmcl", true);
@@ -412,38 +315,20 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const int ci = t0 / ctile;
-#ifdef RRTMG_LW_MERGED
-    if (clouds) {
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
-      (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
-      if (maxrand) hipLaunchKernelGGL((lw_solve_merged_kernel<true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-      else hipLaunchKernelGGL((lw_solve_merged_kernel<false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
-      (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
-    } else {
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
-      hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
-    }
-    if (false) {
-#else
     (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
     hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
     (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
     if (clouds) {
-#endif
       (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
       if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
     }
-    if (unfused_flux) hipLaunchKernelGGL(lw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
-    else hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
+    hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
   ctx->ev_chunks[1] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[3] = clouds ? ctx->ev_chunks[1] : 0;
-  if (unfused_flux) hipLaunchKernelGGL(lw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
-#ifdef RRTMG_LW_PHASES
+#ifdef RRTMG_PROFILE
   {
     unsigned long long ph[16];
     RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));

@@ -39,12 +39,6 @@ constexpr int kLwSlabMaxRows = 2056;   // band 3: 585 + 1175 + 10 + 4 + 171 + 95
 
 // work items of the solve kernel: see SwTab (packed band | ig0 << 8 | G << 16 | first g-point << 20)
 constexpr int kLwMaxItem = 72;
-#ifndef RRTMG_LW_GMAX
-#define RRTMG_LW_GMAX 4
-#endif
-#ifndef RRTMG_LW_G8
-#define RRTMG_LW_G8 0      // experiment: 8 g-points per thread in the bands without a binary species mixture
-#endif
 
 struct LwTab {
   const double *t;
@@ -53,7 +47,7 @@ struct LwTab {
   int32_t item[kLwMaxItem], sched[kLwMaxItem];
   long chirat;             // [CR_N][59] species ratios chi_mls(x, j)/chi_mls(y, j)
   long preflog, tref, chi_mls, totplnk, totplk16, totplnkderiv, totplk16deriv;
-  long exp_tbl, tau_tbl, tfn_tbl, exptfn, delwave;   // exptfn: [index][exp_tbl | tfn_tbl]
+  long exp_tbl, tau_tbl, tfn_tbl, delwave;
   long abscld1, absice0, absice1, absice2, absice3, absliq0, absliq1;
   double heatfac;
 };
@@ -83,10 +77,7 @@ struct LwDev {
   double *scratch;
   double *part;        // [item][nk][nlay+1][pcols], nk = 4 (+2 with idrv): radlu, radld, radclru, radclrd summed over the item
   int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
-  int only_item;       // diagnostic (env RRTMG_HIP_ONLY_ITEM): >= 0 runs this position of the launch order alone (wrong results; timing)
-#ifdef RRTMG_LW_PHASES
-  unsigned long long *phase;   // diagnostic build: [8] shader-clock sums per phase of the sweeps + [8] wave count (lane 0 of every wave)
-#endif
+  RRTMG_PROFILE_FIELDS
   int *err;
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc, *duflx_dt, *duflxc_dt;
 };
@@ -901,18 +892,11 @@ RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
   return p[0] + frac * (p[1] - p[0]);
 }
 
-// Scratch rows per (layer, item).  RRTMG_LW_ONEVAL = 1: ONE row, the gas optical depth of every (layer, g-point) cell; the
+// Scratch rows per (layer, item).  0 = 1: ONE row, the gas optical depth of every (layer, g-point) cell; the
 // upward sweep forms transmittance and source terms again from it (lw_cell) with the layer's Planck terms and Planck
 // fractions recomputed -- half the scratch slab in cloud-free layers, a quarter in cloudy ones.  0: atrans and bbugas
 // (+ atot, bbutot in cloudy layers) as computed by the downward sweep.
-#ifndef RRTMG_LW_ONEVAL
-#define RRTMG_LW_ONEVAL 0
-#endif
-#if RRTMG_LW_ONEVAL
-enum { LF_OD = 0, LF_N };
-#else
 enum { LF_ATRANS = 0, LF_BBUGAS, LF_ATOT, LF_BBUTOT, LF_N };
-#endif
 
 // Per-item radiance sink (host emulation, tests and the device kernel): the band-weighted radiances, summed over
 // the item's g-points, go to part[item][k][level][column], k = 0 up, 1 down, 2 clear up, 3 clear down,
@@ -942,119 +926,76 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   return s;
 }
 
-// quotient of the Pade table index x/(bpade + x): RRTMG_LW_QDIV=1 uses the quick division (see qdiv)
-#ifndef RRTMG_LW_QDIV
-#define RRTMG_LW_QDIV 0
-#endif
-#if RRTMG_LW_QDIV
-#define LW_TDIV(a, b) qdiv((a), (b))
-#else
+// quotient of the Pade table index x/(bpade + x): 0=1 uses the quick division (see qdiv)
 #define LW_TDIV(a, b) ((a) / (b))
-#endif
-#ifdef RRTMG_ABL_UNIFORMLOOKUP
-#define LW_TBLIDX(x) (((int)(x)) & 1)
-#else
 #define LW_TBLIDX(x) ((int)(x))
-#endif
 // Transmittance and Planck source terms of ONE (layer, g-point) cell from its gas optical depth (already times the
 // diffusivity angle, clamped at zero) -- rrtmg_lw_rtrn.f90:342-447 / rrtmg_lw_rtrnmc.f90:342-456.  Both sweeps call it with
 // the same arguments: the downward sweep keeps only the optical depth of every cell (one scratch value instead of
 // atrans + bbugas, + atot + bbutot in cloudy layers), the upward sweep forms its terms again from it.
-struct LwLut { const double *exp_tbl, *tau_tbl, *tfn_tbl, *exptfn; };
+struct LwLut { const double *exp_tbl, *tau_tbl, *tfn_tbl; };
 struct LwCell { double atrans, bbd, bbugas, gassrc, atot, bbdtot, bbutot; };
-RRTMG_HD LwCell lw_cell(const LwLut &lut, bool icldlyr, double odepth, double odcld, double plf, double blay, double dplankdn, double dplankup) {
+// The G cells of one layer at once, WITHOUT data-dependent branches around the table lookups: the reference's
+// "optically thin: series, else: table" (rrtmg_lw_rtrn.f90:426-447) becomes index 0 for the thin lanes, an unconditional
+// gather and a select, so that the G g-points' divisions and gathers are issued back to back and cost ONE trip to the
+// tables per layer instead of one per g-point (a branch with loads in it is not if-converted, and a wave waits for its
+// loads in order).  Same operations on the same operands per lane: identical values.
+// gas part: atrans, bbd, bbugas of the gas optical depth (every layer); cloudy part (CLD, lanes with icldlyr): the terms of
+// gas + cloud (rrtmg_lw_rtrnmc.f90:342-456), whose second lookup depends on the first in the optically thick case.
+template <int G, bool CLD>
+RRTMG_HD void lw_cells(const LwLut &lut, bool icldlyr, const double *odepth_in, const double *odcld, const V<G> &plfv, double blay, double dplankdn,
+                       double dplankup, LwCell *c) {
   const double rec_6 = 0.166667;
-  LwCell c;
-  c.gassrc = 0.0; c.atot = 0.0; c.bbdtot = 0.0; c.bbutot = 0.0;
-  if (icldlyr) {
-    double odtot = odepth + odcld;
-    if (odtot < 0.06) {
-      c.atrans = odepth - 0.5 * odepth * odepth;
-      const double odepth_rec = rec_6 * odepth;
-      c.gassrc = plf * (blay + dplankdn * odepth_rec) * c.atrans;
-      c.atot = odtot - 0.5 * odtot * odtot;
-      const double odtot_rec = rec_6 * odtot;
-      c.bbdtot = plf * (blay + dplankdn * odtot_rec);
-      c.bbd = plf * (blay + dplankdn * odepth_rec);
-      c.bbugas = plf * (blay + dplankup * odepth_rec);
-      c.bbutot = plf * (blay + dplankup * odtot_rec);
-    } else if (odepth <= 0.06) {
-      c.atrans = odepth - 0.5 * odepth * odepth;
-      const double odepth_rec = rec_6 * odepth;
-      c.gassrc = plf * (blay + dplankdn * odepth_rec) * c.atrans;
-      odtot = odepth + odcld;
-      const double tblind = LW_TDIV(odtot, kBpade + odtot);
-      const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
-      const double tfactot = lut.tfn_tbl[ittot];
-      c.bbdtot = plf * (blay + tfactot * dplankdn);
-      c.bbd = plf * (blay + dplankdn * odepth_rec);
-      c.atot = 1.0 - lut.exp_tbl[ittot];
-      c.bbugas = plf * (blay + dplankup * odepth_rec);
-      c.bbutot = plf * (blay + tfactot * dplankup);
-    } else {
-      double tblind = LW_TDIV(odepth, kBpade + odepth);
-      const int itgas = LW_TBLIDX(kTblInt * tblind + 0.5);
-      odepth = lut.tau_tbl[itgas];
-      c.atrans = 1.0 - lut.exp_tbl[itgas];
-      const double tfacgas = lut.tfn_tbl[itgas];
-      c.gassrc = c.atrans * plf * (blay + tfacgas * dplankdn);
-      odtot = odepth + odcld;
-      tblind = LW_TDIV(odtot, kBpade + odtot);
-      const int ittot = LW_TBLIDX(kTblInt * tblind + 0.5);
-      const double tfactot = lut.tfn_tbl[ittot];
-      c.bbdtot = plf * (blay + tfactot * dplankdn);
-      c.bbd = plf * (blay + tfacgas * dplankdn);
-      c.atot = 1.0 - lut.exp_tbl[ittot];
-      c.bbugas = plf * (blay + tfacgas * dplankup);
-      c.bbutot = plf * (blay + tfactot * dplankup);
-    }
-  } else {
-    if (odepth <= 0.06) {
-      c.atrans = odepth - 0.5 * odepth * odepth;
-      odepth = rec_6 * odepth;
-      c.bbd = plf * (blay + dplankdn * odepth);
-      c.bbugas = plf * (blay + dplankup * odepth);
-    } else {
-      const double tblind = LW_TDIV(odepth, kBpade + odepth);
-      const int itr = LW_TBLIDX(kTblInt * tblind + 0.5);
-#if defined(RRTMG_LW_PAIRTBL) && defined(__HIP_DEVICE_COMPILE__)
-      const double2 et = *reinterpret_cast<const double2 *>(lut.exptfn + 2 * (long)itr);
-      const double transc = et.x, tausfac = et.y;
-      c.atrans = 1.0 - transc;
-#else
-      const double transc = lut.exp_tbl[itr];
-      c.atrans = 1.0 - transc;
-      const double tausfac = lut.tfn_tbl[itr];
-#endif
-      c.bbd = plf * (blay + tausfac * dplankdn);
-      c.bbugas = plf * (blay + tausfac * dplankup);
+  bool thin_g[G];
+  int itgas[G];
+  double facgas[G], od_eff[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const double odepth = odepth_in[g];
+    thin_g[g] = odepth <= 0.06;
+    const double tblind = LW_TDIV(odepth, kBpade + odepth);
+    itgas[g] = thin_g[g] ? 0 : LW_TBLIDX(kTblInt * tblind + 0.5);
+  }
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const double odepth = odepth_in[g], plf = plfv[g];
+    const double transc = lut.exp_tbl[itgas[g]], tausfac = lut.tfn_tbl[itgas[g]];
+    c[g].atrans = thin_g[g] ? (odepth - 0.5 * odepth * odepth) : (1.0 - transc);
+    facgas[g] = thin_g[g] ? (rec_6 * odepth) : tausfac;
+    c[g].bbd = plf * (blay + facgas[g] * dplankdn);
+    c[g].bbugas = plf * (blay + facgas[g] * dplankup);
+    od_eff[g] = odepth;
+    if constexpr (CLD) od_eff[g] = thin_g[g] ? odepth : lut.tau_tbl[itgas[g]];
+    c[g].gassrc = 0.0; c[g].atot = 0.0; c[g].bbdtot = 0.0; c[g].bbutot = 0.0;
+  }
+  if constexpr (CLD) {
+    if (icldlyr) {
+      bool thin_t[G];
+      int ittot[G];
+      double odtot[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        // (odtot < 0.06 implies odepth < 0.06: the three cases of the reference are thin/thin, thin/thick, thick/thick)
+        odtot[g] = od_eff[g] + odcld[g];
+        thin_t[g] = thin_g[g] && (odtot[g] < 0.06);
+        const double tblind = LW_TDIV(odtot[g], kBpade + odtot[g]);
+        ittot[g] = thin_t[g] ? 0 : LW_TBLIDX(kTblInt * tblind + 0.5);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double plf = plfv[g];
+        const double transt = lut.exp_tbl[ittot[g]], tfactot = lut.tfn_tbl[ittot[g]];
+        c[g].atot = thin_t[g] ? (odtot[g] - 0.5 * odtot[g] * odtot[g]) : (1.0 - transt);
+        const double factot = thin_t[g] ? (rec_6 * odtot[g]) : tfactot;
+        const double srcdn = blay + facgas[g] * dplankdn;
+        // gassrc = plf*(...)*atrans in the two optically thin cases, atrans*plf*(...) in the thick one: kept as written
+        c[g].gassrc = thin_g[g] ? ((plf * srcdn) * c[g].atrans) : ((c[g].atrans * plf) * srcdn);
+        c[g].bbdtot = plf * (blay + factot * dplankdn);
+        c[g].bbutot = plf * (blay + factot * dplankup);
+      }
     }
   }
-  return c;
 }
-
-// RRTMG_LW_PHASES (diagnostic build, never the product): where a wave's time goes in the two sweeps.  At each phase boundary
-// the wave waits for everything outstanding, so latencies are attributed to the phase that issued the accesses (the
-// overlap the normal schedule gets between phases is lost: the sum is an upper bound of the loop time).
-#if defined(RRTMG_LW_PHASES) && defined(__HIP_DEVICE_COMPILE__)
-#define LW_PH_DECL unsigned long long ph_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_c = __builtin_amdgcn_s_memtime();
-#define LW_PH_MARK(k, pin)                                                              \
-  {                                                                                     \
-    double pin__ = (pin);                                                               \
-    asm volatile("s_waitcnt vmcnt(0) expcnt(0) lgkmcnt(0)" : "+v"(pin__) : : "memory"); \
-    const unsigned long long n__ = __builtin_amdgcn_s_memtime();                        \
-    ph_t[k] += n__ - ph_c; ph_c = n__;                                                  \
-  }
-#define LW_PH_FLUSH                                                                     \
-  if ((threadIdx.x & 63) == 0) {                                                        \
-    for (int k__ = 0; k__ < 8; ++k__) atomicAdd(d.phase + k__, ph_t[k__]);              \
-    atomicAdd(d.phase + 8, 1ull);                                                       \
-  }
-#else
-#define LW_PH_DECL
-#define LW_PH_MARK(k, pin)
-#define LW_PH_FLUSH
-#endif
 // One (column, work item): rtrn / rtrnmc for the item's G g-points (rrtmg_lw_rtrn.f90:324-525).  The layer
 // state, the species mixtures, the Planck functions and the cloud optics are evaluated once for the G g-points.
 // Radiances leave through `sink` weighted by wtdiff*delwave(band) (rrtmg_lw_rtrn.f90:530-543) and summed over
@@ -1068,17 +1009,13 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   const int ib = BAND - 1;
   const int iw0 = T.b[ib].gs + ig0;
   const double *t = T.t;
-  const LwLut lut{t + T.exp_tbl, t + T.tau_tbl, t + T.tfn_tbl, t + T.exptfn};
+  const LwLut lut{t + T.exp_tbl, t + T.tau_tbl, t + T.tfn_tbl};
   const int laytrop = d.laytrop[col];
   const double secd = d.secdiff[(long)ib * N + col];
   const double wtdiff = 0.5, delw = t[T.delwave + ib];
   // scratch slab of this (tile, item): [layer][field][lane][G] -- the G values of a lane are one 16/32-byte access;
   // scr points at this lane's first element, stride = lanes per row (64 on the device, 1 in the host emulation)
-#ifdef RRTMG_ABL_NOSCRATCH
-  auto SP = [&](int f, int l) -> double * { (void)l; return scr + ((long)0 * LF_N + f) * stride * G; };
-#else
   auto SP = [&](int f, int l) -> double * { return scr + ((long)l * LF_N + f) * stride * G; };
-#endif
   auto W = [&](double r) { return (r * wtdiff) * delw; };
 
   // cloud bookkeeping
@@ -1116,51 +1053,24 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; cldrad[g] = 0.0; clrrad[g] = 0.0; radmr[g] = 0.0; }
   if constexpr (CLD) sink.dn(L, 0.0, 0.0); else sink.dn_clear(L, 0.0);
   double tz_up = d.tlev[(long)L * N + col];
-  LW_PH_DECL
-  LW_PH_MARK(0, tz_up)      // 0: setup before the sweep
-#ifdef RRTMG_LW_LATEPREFETCH
-  // The layer's prep rows are requested one layer AHEAD -- but only once taumol has consumed the current layer's rows, so
-  // that the registers they arrive in are the ones the current rows just vacated: the rows fly while the table lookups, the
-  // recurrence and the stores of this layer run (an earlier attempt requested them at the top of the iteration, where both
-  // layers' rows were live through taumol: spills).  The scheduling barrier keeps the compiler from hoisting the loads.
-  LwLayerIn s;
-  lw_load_layer(d, col, L - 1, s);
-#endif
+  RRTMG_PH_DECL
+  RRTMG_PH_MARK(0, tz_up)      // 0: setup before the sweep
   for (int lev = L; lev >= 1; --lev) {
     const int l = lev - 1;
     const long i = (long)l * N + col;
-#ifndef RRTMG_LW_LATEPREFETCH
     LwLayerIn s;
     lw_load_layer(d, col, l, s);
-#endif
-    LW_PH_MARK(1, s.fac00 + s.colh2o + (double)s.jp)      // 1: the layer's prep rows have arrived
+    RRTMG_PH_MARK(1, s.fac00 + s.colh2o + (double)s.jp)      // 1: the layer's prep rows have arrived
     V<G> plfrac;
-#ifdef RRTMG_ABL_NOTAUG
-    plfrac = vsplat<G>(0.1); const V<G> taug = vsplat<G>(s.colh2o * 1.0e-3 + s.fac00);
-#else
     const V<G> taug = lw_taug<BAND, G, LDSK>(T, s, lev <= laytrop, ig0, plfrac, kb);
-#endif
-    LW_PH_MARK(2, taug[0] + taug[G - 1] + plfrac[0])      // 2: taumol (LDS row gathers + arithmetic)
-#if defined(RRTMG_LW_LATEPREFETCH)
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-    if (lev > 1) lw_load_layer(d, col, l - 1, s);
-#if defined(__HIP_DEVICE_COMPILE__)
-    __builtin_amdgcn_sched_barrier(0);
-#endif
-#endif
+    RRTMG_PH_MARK(2, taug[0] + taug[G - 1] + plfrac[0])      // 2: taumol (LDS row gathers + arithmetic)
     const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
     const double tz_dn = d.tlev[i];
-#ifdef RRTMG_ABL_NOPLANCK
-    const double blay = d.tlay[i], dplankup = tz_up - blay, dplankdn = tz_dn - blay;
-#else
     const double blay = lw_planck(T, ib, d.tlay[i]);
     const double dplankup = lw_planck(T, ib, tz_up) - blay;
     const double dplankdn = lw_planck(T, ib, tz_dn) - blay;
-#endif
     tz_up = tz_dn;
-    LW_PH_MARK(3, blay + dplankup + dplankdn + taua)      // 3: aerosol / temperature rows and the three Planck interpolations
+    RRTMG_PH_MARK(3, blay + dplankup + dplankdn + taua)      // 3: aerosol / temperature rows and the three Planck interpolations
     // band-level cloud state of this layer (shared by the g-points)
     bool icldlyr = false, cld_band = false;
     double cfrac_band = 0.0, odcld_band = 0.0, efcl_band = 0.0;
@@ -1190,23 +1100,30 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     }
     double srd = 0.0, srcd = 0.0;
     V<G> v_atrans, v_bbugas, v_atot, v_bbutot, v_od;
+    double cfrac_g[G], odcld_g[G], efcl_g[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const double plf = plfrac[g];
       const double taut = taug[g] + taua;
       double odepth = secd * taut;
       if (odepth < 0.0) odepth = 0.0;
-      double cfrac = 0.0, odcld = 0.0, efclfrac = 0.0;
+      v_od[g] = odepth;
+      cfrac_g[g] = 0.0; odcld_g[g] = 0.0; efcl_g[g] = 0.0;
       if (icldlyr) {
         if (d.mcica) {
-          if ((mw[g] >> (l & 63)) & 1ull) { cfrac = 1.0; odcld = odcld_band; efclfrac = efcl_band; }
+          if ((mw[g] >> (l & 63)) & 1ull) { cfrac_g[g] = 1.0; odcld_g[g] = odcld_band; efcl_g[g] = efcl_band; }
         } else if (cld_band) {
-          cfrac = cfrac_band; odcld = odcld_band; efclfrac = efcl_band;
+          cfrac_g[g] = cfrac_band; odcld_g[g] = odcld_band; efcl_g[g] = efcl_band;
         }
       }
-      const LwCell c = lw_cell(lut, icldlyr, odepth, odcld, plf, blay, dplankdn, dplankup);
+    }
+    LwCell cells[G];
+    lw_cells<G, CLD>(lut, icldlyr, v_od.v, odcld_g, plfrac, blay, dplankdn, dplankup, cells);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double plf = plfrac[g];
+      const double cfrac = cfrac_g[g], efclfrac = efcl_g[g];
+      const LwCell &c = cells[g];
       const double atrans = c.atrans, bbd = c.bbd, bbugas = c.bbugas;
-      v_od[g] = odepth;
       if (icldlyr) {
         iclddn[g] = 1;
         const double gassrc = c.gassrc, atot = c.atot, bbdtot = c.bbdtot, bbutot = c.bbutot;
@@ -1240,18 +1157,13 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       srd = srd + W(radld[g]); srcd = srcd + W(radclrd[g]);
       plfrac_bot[g] = plf;
     }
-    LW_PH_MARK(4, radld[0] + radld[G - 1] + srd)      // 4: table index, exp/tfn lookups, recurrence of the G g-points
-#if RRTMG_LW_ONEVAL
-    scr_store<G>(SP(LF_OD, l), stride, v_od);
-    (void)v_atrans; (void)v_bbugas; (void)v_atot; (void)v_bbutot;
-#else
+    RRTMG_PH_MARK(4, radld[0] + radld[G - 1] + srd)      // 4: table index, exp/tfn lookups, recurrence of the G g-points
     scr_store<G>(SP(LF_ATRANS, l), stride, v_atrans);
     scr_store<G>(SP(LF_BBUGAS, l), stride, v_bbugas);
     if (icldlyr) { scr_store<G>(SP(LF_ATOT, l), stride, v_atot); scr_store<G>(SP(LF_BBUTOT, l), stride, v_bbutot); }
     (void)v_od;
-#endif
     if constexpr (CLD) sink.dn(lev - 1, srd, srcd); else sink.dn_clear(lev - 1, srd);
-    LW_PH_MARK(5, srd)      // 5: scratch rows and partial sums stored
+    RRTMG_PH_MARK(5, srd)      // 5: scratch rows and partial sums stored
   }
 
   // ---- surface ------------------------------------------------------------------------------
@@ -1278,22 +1190,12 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
   }
 
   // ---- upward sweep: kU layers at a time, their scratch rows are loaded before the first is used ----------
-#ifndef RRTMG_LW_KU
-#define RRTMG_LW_KU 4
-#endif
-  constexpr int kU = G == 8 ? 2 : RRTMG_LW_KU;
+  constexpr int kU = 4;
   for (int lev0 = 1; lev0 <= L; lev0 += kU) {
-#if RRTMG_LW_ONEVAL
-    V<G> r_od[kU];
-#pragma unroll
-    for (int u = 0; u < kU; ++u)
-      if (lev0 + u <= L) r_od[u] = scr_load<G>(SP(LF_OD, lev0 + u - 1), stride);
-#else
     V<G> r_atrans[kU], r_bbugas[kU];
 #pragma unroll
     for (int u = 0; u < kU; ++u)
       if (lev0 + u <= L) { r_atrans[u] = scr_load<G>(SP(LF_ATRANS, lev0 + u - 1), stride); r_bbugas[u] = scr_load<G>(SP(LF_BBUGAS, lev0 + u - 1), stride); }
-#endif
 #pragma unroll
     for (int u = 0; u < kU; ++u) {
       const int lev = lev0 + u;
@@ -1318,23 +1220,8 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
           }
         }
       }
-#if RRTMG_LW_ONEVAL
-      // the layer's Planck terms and Planck fractions again (the optical depths come from the scratch row): the taumol
-      // arithmetic of lw_taug that feeds only `taug` is dead here and falls out at compile time
-      V<G> plfrac_u;
-      double blay_u, dplankup_u;
-      {
-        LwLayerIn su;
-        lw_load_layer(d, col, l, su);
-        (void)lw_taug<BAND, G, LDSK>(T, su, lev <= laytrop, ig0, plfrac_u, kb);
-        const long i = (long)l * N + col;
-        blay_u = lw_planck(T, ib, d.tlay[i]);
-        dplankup_u = lw_planck(T, ib, d.tlev[i + N]) - blay_u;
-      }
-#else
       V<G> r_atot, r_bbutot;
       if (icldlyr) { r_atot = scr_load<G>(SP(LF_ATOT, l), stride); r_bbutot = scr_load<G>(SP(LF_BBUTOT, l), stride); }
-#endif
       double mr_start = 0.0, mr_clr1 = 0.0, mr_cld1 = 0.0, mr_cmb1 = 0.0, mr_cmb2 = 0.0, mr_clr2 = 0.0, mr_cld2 = 0.0;
       if (MR && icldlyr) {
         mr_start = d.mr[lw_mr_off(L, col, lev) + MR_ISTCLD * 64];
@@ -1343,29 +1230,24 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
         mr_clr2 = q[MR_FACCLR2 * 64]; mr_cld2 = q[MR_FACCLD2 * 64];
       }
       double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      double cfrac_g[G], odcld_g[G], efcl_g[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        double cfrac = 0.0, efclfrac = 0.0, odcld = 0.0;
+        cfrac_g[g] = 0.0; odcld_g[g] = 0.0; efcl_g[g] = 0.0;
         if (icldlyr) {
           if (d.mcica) {
-            if ((mw[g] >> (l & 63)) & 1ull) { cfrac = 1.0; efclfrac = efcl_band; odcld = odcld_band; }
+            if ((mw[g] >> (l & 63)) & 1ull) { cfrac_g[g] = 1.0; efcl_g[g] = efcl_band; odcld_g[g] = odcld_band; }
           } else if (cld_band) {
-            cfrac = cfrac_band; efclfrac = efcl_band; odcld = odcld_band;
+            cfrac_g[g] = cfrac_band; efcl_g[g] = efcl_band; odcld_g[g] = odcld_band;
           }
         }
-#if RRTMG_LW_ONEVAL
-        const LwCell c = lw_cell(lut, icldlyr, r_od[u][g], odcld, plfrac_u[g], blay_u, 0.0, dplankup_u);
-        const double atrans = c.atrans, bbugas = c.bbugas;
-#else
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        const double cfrac = cfrac_g[g], efclfrac = efcl_g[g];
         const double atrans = r_atrans[u][g], bbugas = r_bbugas[u][g];
-        (void)odcld;
-#endif
         if (icldlyr) {
-#if RRTMG_LW_ONEVAL
-          const double atot = c.atot, bbutot = c.bbutot;
-#else
           const double atot = r_atot[g], bbutot = r_bbutot[g];
-#endif
           const double gassrc = bbugas * atrans;
           if constexpr (MR) {
             if (mr_start == 1.0) { cldrad[g] = cfrac * radlu[g]; clrrad[g] = radlu[g] - cldrad[g]; radmr[g] = 0.0; }
@@ -1399,22 +1281,18 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
       if constexpr (CLD) sink.up(lev, s0, s1, s2, s3); else sink.up_clear(lev, s0, s2);
     }
   }
-  LW_PH_MARK(6, radlu[0])      // 6: surface + the whole upward sweep
-  LW_PH_FLUSH
+  RRTMG_PH_MARK(6, radlu[0])      // 6: surface + the whole upward sweep
+  RRTMG_PH_FLUSH(d)
 }
 
 // Dispatch of one work item (packed, see LwTab) for one column: band switch + G in {4, 2}.
 template <int BAND, bool CLD, bool MR, bool LDSK, class Sink>
 RRTMG_HD void lw_solve_band(const LwDev &d, const LwTab &T, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = kLwNg[BAND - 1];
-  constexpr bool simple = BAND == 1 || BAND == 2 || BAND == 6 || BAND == 8 || BAND == 10 || BAND == 11 || BAND == 14;
-  if constexpr (RRTMG_LW_G8 && simple && ng >= 8) {
-    if (g == 8) { lw_solve_thread<BAND, 8, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb); return; }
-  }
-  if constexpr (ng >= 4 && RRTMG_LW_GMAX >= 4) {
+  if constexpr (ng >= 4) {
     if (g == 4) { lw_solve_thread<BAND, 4, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb); return; }
   }
-  if constexpr (ng % 4 != 0 || RRTMG_LW_GMAX < 4) lw_solve_thread<BAND, 2, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb);
+  if constexpr (ng % 4 != 0) lw_solve_thread<BAND, 2, CLD, MR, LDSK>(d, T, col, ig0, scr, stride, sink, kb);
 }
 // LDSK / kb: see lw_taug (kb = the workgroup's LDS slice of the item's band slab, or nullptr with LDSK = false)
 template <bool CLD, bool MR, bool LDSK = false, class Sink>

@@ -66,14 +66,6 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
   T.totplnkderiv = off("lw/wvn/totplnkderiv", true); T.totplk16deriv = off("lw/wvn/totplk16deriv", true);
   T.exp_tbl = off("lw/tbl/exp_tbl", true); T.tau_tbl = off("lw/tbl/tau_tbl", true); T.tfn_tbl = off("lw/tbl/tfn_tbl", true);
   T.delwave = off("lw/wvn/delwave", true);
-  {
-    // transmittance and tau-transition entries of one index side by side: the clear-sky lookup of a (layer, g-point) reads
-    // exp_tbl[i] AND tfn_tbl[i] -- one 16-byte gather instead of two 8-byte ones from different cache lines
-    const long n = ts.reg["lw/tbl/exp_tbl"].n;
-    std::vector<double> et((size_t)2 * n);
-    for (long i = 0; i < n; ++i) { et[2 * i] = ts.flat[(size_t)T.exp_tbl + i]; et[2 * i + 1] = ts.flat[(size_t)T.tfn_tbl + i]; }
-    T.exptfn = ts.add("lw/tbl/exptfn", et.data(), (long)et.size(), {2u, (uint32_t)n});
-  }
   T.abscld1 = off("lw/cld/abscld1", true); T.absice0 = off("lw/cld/absice0", true); T.absice1 = off("lw/cld/absice1", true);
   T.absice2 = off("lw/cld/absice2", true); T.absice3 = off("lw/cld/absice3", true); T.absliq0 = off("lw/cld/absliq0", true);
   T.absliq1 = off("lw/cld/absliq1", true);
@@ -94,9 +86,9 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
   for (int b = 0; b < kLwNBand; ++b) {
     int ig = 0;
     while (ig < T.b[b].ng) {
-      // (RRTMG_LW_G8: the bands without a binary species mixture -- few table rows, little layer state -- in chunks of 8)
-      const int g = (RRTMG_LW_G8 && nspa[b] == 1 && T.b[b].ng - ig >= 8) ? 8 : (T.b[b].ng - ig >= 4 && RRTMG_LW_GMAX >= 4) ? 4 : 2;
-      if ((long)T.b[b].nrows * g > (long)kLwSlabMaxRows * RRTMG_LW_GMAX) { err = "work item slice does not fit the LDS buffer"; return false; }
+      // (0: the bands without a binary species mixture -- few table rows, little layer state -- in chunks of 8)
+      const int g = (0 && nspa[b] == 1 && T.b[b].ng - ig >= 8) ? 8 : (T.b[b].ng - ig >= 4 && 4 >= 4) ? 4 : 2;
+      if ((long)T.b[b].nrows * g > (long)kLwSlabMaxRows * 4) { err = "work item slice does not fit the LDS buffer"; return false; }
       if (T.nitem >= kLwMaxItem) { err = "too many work items"; return false; }
       cost[T.nitem] = (nspa[b] == 9 ? 2.0 : 1.0) + g * 0.7;
       T.item[T.nitem] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);

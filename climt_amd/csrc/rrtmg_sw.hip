@@ -3,7 +3,7 @@
 // Launch sequence of one rrtmg_hip_sw_fluxes call (all on the context's shortwave stream):
 //   sw_prep_fused_kernel <<<tiles, 16 waves>>>   inatm_sw + setcoef_sw per (column, layer), then the column part from the index
 //                        words in LDS (laytrop, cloud flag, solar-source layer per band); non-McICA cloudy tiles: the band cloud
-//                        optics           (RRTMG_HIP_UNFUSED=1: sw_prep_layer_kernel, sw_prep_kernel, sw_cloud_kernel)
+//                        optics
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
 //   sw_cloud_kernel     (McICA)                  band cloud optics per (column, layer)
 //   kiss_mask_kernel / mask upload (McICA)       sub-column cloud mask
@@ -11,7 +11,6 @@
 //     sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel (cloudy tiles): wavefront = tile(64 columns) x work
 //                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS
 //     sw_fluxheat_kernel  <<<(tiles, levels/15), 16 waves>>>  g-point sum per interface + heating rates
-//                         (RRTMG_HIP_UNFUSED=2: sw_flux_kernel + sw_heat_kernel)
 #include "rrtmg_ctx.h"
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
@@ -19,30 +18,12 @@
 
 namespace rrtmg {
 
-__global__ void __launch_bounds__(64) sw_prep_layer_kernel(SwDev d, SwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_prep_layer(d, T, col, blockIdx.y);
-}
-__global__ void __launch_bounds__(64) sw_prep_kernel(SwDev d, SwTab T) {   // grid (tiles, bands)
-  const int col = blockIdx.x * 64 + threadIdx.x, b = blockIdx.y;
-  if (col < d.ncol) sw_prep_column(d, T, col, b, b + 1);
-  if (b != 0) return;
-  // tile flag: does any column of this 64-column tile have a cloud? (selects the solve kernel variant)
-  const bool cld = col < d.ncol && d.anycld[col] != 0;
-  const unsigned long long any = __ballot(cld);
-  if (threadIdx.x == 0) d.tile_cld[blockIdx.x] = any != 0ull;
-}
-
-// The three kernels above in ONE launch (the default; RRTMG_HIP_UNFUSED=1 keeps the separate ones): a workgroup = one
-// 64-column tile, 16 wavefronts.  Phase 1: wave w prepares layers w, w+16, ...; phase 2, behind a barrier: wave b runs
+// Preparation in ONE launch (round 1: three kernels): a workgroup = one 64-column tile, 16 wavefronts.  Phase 1: wave w prepares layers w, w+16, ...; phase 2, behind a barrier: wave b runs
 // band b's column bookkeeping on the rows just written (L2-hot) and wave 0 sets the tile's cloud flag; phase 3, in cloudy
 // tiles of a non-McICA call: the band cloud optics, again layers strided over the waves (with McICA, where most tiles are
 // cloudy, the optics stay a launch of their own over (tile, layer): one workgroup per tile was measured 5 % slower on the
 // whole McICA step).  Same per-thread functions, same results.
-#ifndef RRTMG_PREP_WAVES
-#define RRTMG_PREP_WAVES 16
-#endif
-constexpr int kPrepWaves = RRTMG_PREP_WAVES;
+constexpr int kPrepWaves = 16;
 __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d, SwTab T, int clouds) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
@@ -106,19 +87,10 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 // cost a tag lookup per lane in the vector L1, but only bank conflicts in LDS; (b) the item's k-distribution slice,
 // columns ig0..ig0+G-1 of the band's table slab, [nrows][G] (<= 58 KB): every absorption-coefficient row a lane
 // needs is a 32-byte LDS read instead of a per-lane gather through the vector L1's 64 B/clk return path
-// (measured: -6 % kernel time; with the rows through the scalar cache, RRTMG_ABL_SCALARK, -10 % was the bound).
+// (measured: -6 % kernel time; with the rows through the scalar cache, an ablation, -10 % was the bound).
 // Launch order: items heaviest first (SwTab::sched), tile groups fastest.  Speed only, never correctness.
-#ifndef RRTMG_SW_WAVES
-#define RRTMG_SW_WAVES 4
-#endif
-#ifndef RRTMG_SW_WGWAVES
-#define RRTMG_SW_WGWAVES 16
-#endif
-constexpr int kSwWgWaves = RRTMG_SW_WGWAVES;
+constexpr int kSwWgWaves = 16;
 constexpr int kExpTblN = 10001;
-#ifndef RRTMG_SW_KLDS
-#define RRTMG_SW_KLDS 1      // clear-sky kernel: the item's k-distribution slice in LDS next to the 80 KB table (one workgroup per CU)
-#endif
 // the item's slice of its band's table slab -> LDS: columns ig0 .. ig0+G-1, [nrows][G] (see SwBandTab)
 __device__ __forceinline__ void sw_stage_slice(const SwTab &T, int item, double *sh_k, int nthreads) {
   const SwBandTab &B = T.b[item_band(item)];
@@ -131,7 +103,7 @@ __device__ __forceinline__ void sw_stage_slice(const SwTab &T, int item, double 
 // (CLD = false: no spills, chunks of 4 g-points), sw_solve_cloudy_kernel the tiles flagged by sw_prep_kernel; a
 // wavefront whose tile belongs to the other kernel exits at once.
 template <bool CLD>
-__global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SW_WAVES))) sw_solve_all_kernel(SwDev d, SwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
+__global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(4))) sw_solve_all_kernel(SwDev d, SwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x;
   {
@@ -143,109 +115,27 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
     }
     if (!mine) return;
   }
-#ifdef RRTMG_SW_NOLDS
-  const double *sh_exp = T.t + T.exp_tbl;
-#else
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
-#endif
   const int k = q / ngrp;
-  if (d.only_item >= 0 && k != d.only_item) return;
-  const int id = T.sched[CLD ? 1 : 0][k], item = T.item[CLD ? 1 : 0][id], slot = CLD ? (item_iw0(item) >> 1) : id;
-#if RRTMG_SW_KLDS
+  RRTMG_PROFILE_ONLY_ITEM(d, k)
+  const int id = T.sched[k], item = T.item[id], slot = id;
   constexpr bool kLdsK = true;
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];   // rows are read 16 bytes at a time
   sw_stage_slice(T, item, sh_k, 64 * kSwWgWaves);
-#else
-  constexpr bool kLdsK = false;
-  const double *sh_k = nullptr;
-#endif
-#if !defined(RRTMG_SW_NOLDS) || RRTMG_SW_KLDS
   __syncthreads();
-#endif
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ctile = (q % ngrp) * kSwWgWaves + wave;   // tile within the chunk
   const int tile = tile0 + ctile;
   if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? (threadIdx.x & 63) * 2 : (threadIdx.x & 63) * item_g(item));
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * 2;
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<CLD, kLdsK>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
 
-#if !RRTMG_SWC_G4   // the round-1 kernel for the cloudy tiles, kept as a build switch (RRTMG_SWC_G4=0)
-// The cloudy tiles: both sky streams per g-point need ~170 VGPRs, which does not go with the 128-VGPR cap of the clear-sky
-// kernel's 4 waves/SIMD (spills: measured +30 %): 3 waves/SIMD here.  Workgroup = 12 wavefronts = the same pair of
-// g-points for 12 consecutive tiles, one workgroup per CU, sharing in LDS the transmittance table (80 KB) and the pair's
-// k-distribution slice ([nrows][2], <= 29 KB): per-lane row reads and table lookups cost bank conflicts only, not the
-// vector L1's return path.  (4-wave workgroups with the slice alone, three per CU, measured 1-4 % slower.)
-#ifndef RRTMG_SWC_WGWAVES
-#define RRTMG_SWC_WGWAVES 12
-#endif
-#ifndef RRTMG_SWC_EXPLDS
-#define RRTMG_SWC_EXPLDS 1
-#endif
-constexpr int kSwCldWgWaves = RRTMG_SWC_WGWAVES;
-#ifndef RRTMG_SWC_WAVES
-#define RRTMG_SWC_WAVES 3
-#endif
-#ifndef RRTMG_SWC_XCD
-#define RRTMG_SWC_XCD 0
-#endif
-__global__ void __launch_bounds__(64 * kSwCldWgWaves) __attribute__((amdgpu_waves_per_eu(RRTMG_SWC_WAVES))) sw_solve_cloudy_pairs_kernel(SwDev d, SwTab T, int tile0, int ntile) {
-  // launch order: tile groups, within a group the items heaviest first -- the group's prep rows (12 tiles x 0.46 MB) are
-  // fetched while its 56 items run, instead of the whole prep slab once per item
-  const int q = blockIdx.x;
-#if RRTMG_SWC_XCD == 2
-  // XCD-aware order (speed only): block q is observed to run on XCD q % 8, each XCD with its own 4 MB L2.  The group-major
-  // sequence s = group * nitem + k is cut into eight equal contiguous runs, one per XCD (nitem = 56 is a multiple of 8, so
-  // the cut is exact): every XCD gets the same number of workgroups, and a tile group's prep rows are fetched into one L2
-  // (two where a run boundary falls inside the group) instead of all eight.
-  const int per = (int)(gridDim.x >> 3);
-  const int sidx = (q & 7) * per + (q >> 3);
-  const int ctile0 = (sidx / T.nitem[1]) * kSwCldWgWaves, k = sidx % T.nitem[1];
-#elif RRTMG_SWC_XCD
-  // (first attempt, kept as a switch: whole tile groups dealt round-robin to the XCDs -- unbalanced unless the group
-  // count is a multiple of 8: measured slower at 8192 columns)
-  const int ngrp = (ntile + kSwCldWgWaves - 1) / kSwCldWgWaves;
-  const int grp = ((q >> 3) / T.nitem[1]) * 8 + (q & 7), k = (q >> 3) % T.nitem[1];
-  if (grp >= ngrp) return;
-  const int ctile0 = grp * kSwCldWgWaves;
-#else
-  const int ctile0 = (q / T.nitem[1]) * kSwCldWgWaves, k = q % T.nitem[1];
-#endif
-  {
-    bool mine = false;
-    for (int w = 0; w < kSwCldWgWaves; ++w)
-      if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
-    if (!mine) return;
-  }
-  if (d.only_item >= 0 && k != d.only_item) return;
-  const int id = T.sched[1][k], item = T.item[1][id], slot = item_iw0(item) >> 1;
-  __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 2];
-  sw_stage_slice(T, item, sh_k, 64 * kSwCldWgWaves);
-#if RRTMG_SWC_EXPLDS
-  __shared__ double sh_exp[kExpTblN];
-  for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwCldWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
-#else
-  const double *sh_exp = T.t + T.exp_tbl;
-#endif
-  __syncthreads();
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = ctile0 + wave, tile = tile0 + ctile;
-  if (ctile >= ntile || !d.tile_cld[tile]) return;
-  const int lane = threadIdx.x & 63;
-  const int col = tile * 64 + lane;
-  if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * item_g(item));
-  SwPartSink sink = sw_part_sink(d, slot, col);
-  sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
-}
 
-#endif
-
-#if RRTMG_SWC_G4
 // The cloudy tiles (flagged by the preparation kernel): both sky streams per g-point.  They run the CLEAR kernel's item set
 // -- chunks of 4 g-points, so the item-invariant work (layer state, species mixtures, weights, row indices) is paid once per
 // 4 g-points, not per pair -- at 2 waves/SIMD: 238 VGPRs, no spills; 8-wave workgroups, one per CU, sharing the
@@ -262,8 +152,8 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
       if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
     if (!mine) return;
   }
-  if (d.only_item >= 0 && k != d.only_item) return;
-  const int id = T.sched[0][k], item = T.item[0][id], slot = id;      // one slot per chunk (sw_flux_sums mode 2)
+  RRTMG_PROFILE_ONLY_ITEM(d, k)
+  const int id = T.sched[k], item = T.item[id], slot = id;      // one slot per chunk
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
   sw_stage_slice(T, item, sh_k, 64 * kC4Waves);
   __shared__ double sh_exp[kExpTblN];
@@ -275,21 +165,11 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
-  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (RRTMG_SCR_PAIRMAJOR ? lane * 2 : lane * item_g(item));
+  double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + lane * 2;
   SwPartSink sink = sw_part_sink(d, slot, col);
   sw_solve_item<true, true>(d, T, sh_exp, item, col, scr, 64, sink, sh_k);
 }
-#endif
 
-constexpr int kSwCldFluxMode = RRTMG_SWC_G4 ? 2 : 1;   // how the cloudy tiles' partial planes are laid out (sw_flux_sums)
-__global__ void __launch_bounds__(64) sw_flux_kernel(SwDev d, SwTab T, int tile0) {
-  const int tile = tile0 + blockIdx.x, col = tile * 64 + threadIdx.x;
-  if (col < d.ncol) sw_flux_level(d, T, col, blockIdx.y, d.tile_cld[tile] != 0 ? kSwCldFluxMode : 0);
-}
-__global__ void __launch_bounds__(64) sw_heat_kernel(SwDev d, SwTab T) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < d.ncol) sw_heat_layer(d, T, col, blockIdx.y);
-}
 // Spectral integration AND heating rates in one launch: a workgroup = one tile x kFluxLev layers; wave j sums the partial
 // planes of interface level l0 + j (the extra wave kFluxLev: the halo level on top, recomputed by the next workgroup, which
 // owns and stores it), the net fluxes meet in LDS, waves j < kFluxLev form the layer's heating rates from levels j and j + 1
@@ -302,7 +182,7 @@ __global__ void __launch_bounds__(64 * (kFluxLev + 1)) sw_fluxheat_kernel(SwDev 
   const bool act = col < d.ncol && lev <= d.nlay;
   if (act) {
     double fu, fd, cu, cd;
-    sw_flux_sums(d, T, col, lev, d.tile_cld[tile] != 0 ? kSwCldFluxMode : 0, fu, fd, cu, cd);
+    sw_flux_sums(d, T, col, lev, d.tile_cld[tile] != 0, fu, fd, cu, cd);
     if (j < kFluxLev || lev == d.nlay) {
       const long o = (long)lev * d.ncol + col;
       d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
@@ -404,8 +284,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (d.iaer != 0 && d.iaer != 6 && d.iaer != 10) d.iaer = 0;
   d.inflag = a->inflgsw; d.iceflag = a->iceflgsw; d.liqflag = a->liqflgsw; d.mcica = a->mcica ? 1 : 0;
   d.k = ctx->k;
-  d.only_item = -1;
-  if (const char *e = getenv("RRTMG_HIP_ONLY_ITEM")) d.only_item = atoi(e);
+  RRTMG_PROFILE_READ_ONLY_ITEM(d)
   std::string err;
   std::vector<double> svar_col;
   {
@@ -497,15 +376,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 
   // ---- launches ---------------------------------------------------------------------------
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
-  // RRTMG_HIP_UNFUSED (A/B; same results): bit 0 = separate preparation kernels, bit 1 = separate flux and heating-rate kernels
-  static const int unfused_bits = getenv("RRTMG_HIP_UNFUSED") ? atoi(getenv("RRTMG_HIP_UNFUSED")) : 0;
-  const bool unfused = unfused_bits & 1, unfused_flux = unfused_bits & 2;
-  if (unfused) {
-    hipLaunchKernelGGL(sw_prep_layer_kernel, gcl, blk, 0, s, d, T);
-    hipLaunchKernelGGL(sw_prep_kernel, dim3(ntile, kSwNBand), blk, 0, s, d, T);
-  } else {
-    hipLaunchKernelGGL(sw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0);
-  }
+  hipLaunchKernelGGL(sw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0);
   if (d.iaer == 6) {
     double *ta = wd("aer.tau", nl * kSwNBand), *om = wd("aer.ssa", nl * kSwNBand), *as = wd("aer.asm", nl * kSwNBand);
     if (!ok) return ctx->status;
@@ -513,7 +384,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     d.tauaer = ta; d.ssaaer = om; d.asmaer = as;
   }
   if (clouds) {
-    if (unfused || d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, gcl, blk, 0, s, d, T);
+    if (d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, gcl, blk, 0, s, d, T);
     if (d.mcica) {
       if (a->cldfmcl) {
         const double *cm = in(a->cldfmcl, nl * kSwNGpt, "cldfmcl", true);
@@ -543,26 +414,16 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     const dim3 wg(64 * kSwWgWaves);
     const int ci = t0 / ctile;
     (void)hipEventRecord(ctx->chunk_event(0, ci, 0), s);
-    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem[0]), wg, 0, s, d, T, t0, nt);
+    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem), wg, 0, s, d, T, t0, nt);
     (void)hipEventRecord(ctx->chunk_event(0, ci, 1), s);
     if (clouds) {
       (void)hipEventRecord(ctx->chunk_event(2, ci, 0), s);
-#if !RRTMG_SWC_G4
-      const int cgrp = (nt + kSwCldWgWaves - 1) / kSwCldWgWaves;
-      const int cgrid = (RRTMG_SWC_XCD == 1 ? (cgrp + 7) / 8 * 8 : cgrp) * T.nitem[1];
-#endif
-#if RRTMG_SWC_G4
-      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem[0]), dim3(64 * kC4Waves), 0, s, d, T, t0, nt);
-#else
-      hipLaunchKernelGGL(sw_solve_cloudy_pairs_kernel, dim3(cgrid), dim3(64 * kSwCldWgWaves), 0, s, d, T, t0, nt);
-#endif
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem), dim3(64 * kC4Waves), 0, s, d, T, t0, nt);
       (void)hipEventRecord(ctx->chunk_event(2, ci, 1), s);
     }
-    if (unfused_flux) hipLaunchKernelGGL(sw_flux_kernel, dim3(nt, L + 1), blk, 0, s, d, T, t0);
-    else hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
+    hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
   ctx->ev_chunks[0] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[2] = clouds ? ctx->ev_chunks[0] : 0;
-  if (unfused_flux) hipLaunchKernelGGL(sw_heat_kernel, gcl, blk, 0, s, d, T);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 
   // ---- status + outputs -------------------------------------------------------------------

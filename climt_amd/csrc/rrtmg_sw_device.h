@@ -42,15 +42,13 @@ struct SwBandTab {
 };
 constexpr int kSwSlabMaxRows = 1800;   // bands 17 / 21 / 28: 585 + 1175 + 10 + 4 + ... rows (checked at init)
 
-// Work item of the solve kernel: G (4 or 2) consecutive g-points of one band, carried by one thread per column.
-// Packed band | ig0 << 8 | G << 16 | (first g-point of the whole spectrum) << 20.  Two item sets: set 0 (chunks of
-// 4, then 2) for the clear-sky kernel variant, set 1 (pairs) for the cloudy one, whose per-g-point state is twice
-// as large.  sched[] lists a set's items heaviest first (launch order).  Partial fluxes: a cloudy tile writes one
-// slot per PAIR of g-points (slot = first g-point / 2, kSwNSlot slots); a clear tile one slot per CHUNK (= item of
-// set 0), holding (pair0 + pair1).  The flux kernel adds chunk sums, forming (pair0 + pair1) itself for cloudy
-// tiles -- the 112 g-points are added in the same order whichever variant a tile ran.
-constexpr int kSwMaxItem = 56;
-constexpr int kSwNSlot = 56;
+// Work item of the solve kernel: G consecutive g-points of one band -- chunks of 4, then 2 where a band's count is not a
+// multiple of 4 -- carried by one thread per column.  Packed band | ig0 << 8 | G << 16 | (first g-point of the whole
+// spectrum) << 20.  sched[] lists the items heaviest first (launch order).  Partial fluxes: one slot per item, holding
+// the sum of its pairs, (pair0 + pair1); the flux kernel adds the slots in item order -- the 112 g-points are added in the
+// same order whichever kernel variant (cloud-free / cloudy tile) a tile ran.
+constexpr int kSwMaxItem = 32;
+constexpr int kSwNSlot = 32;
 RRTMG_HD int item_band(int it) { return it & 0xff; }
 RRTMG_HD int item_ig0(int it) { return (it >> 8) & 0xff; }
 RRTMG_HD int item_g(int it) { return (it >> 16) & 0xf; }
@@ -59,9 +57,8 @@ RRTMG_HD int item_iw0(int it) { return (it >> 20) & 0xff; }
 struct SwTab {
   const double *t;
   SwBandTab b[kSwNBand];
-  int nitem[2];
-  int32_t item[2][kSwMaxItem], sched[2][kSwMaxItem];
-  int32_t chunk_pair0[kSwMaxItem], chunk_npair[kSwMaxItem];   // per chunk (item of set 0): first pair slot, pairs (2 | 1)
+  int nitem;
+  int32_t item[kSwMaxItem], sched[kSwMaxItem];
   long preflog, tref, exp_tbl;
   long extliq1, ssaliq1, asyliq1, extice2, ssaice2, asyice2, extice3, ssaice3, asyice3, fdlice3;
   long abari, bbari, cbari, dbari, ebari, fbari, wavenum2;
@@ -99,7 +96,7 @@ struct SwDev {
   double *scratch;     // [tile][item: first g-point * ...][lay][field][G][64]
   double *part;        // [slot][4][nlay+1][pcols]  weighted (fu, fd, cu, cd) of the columns col0 .. col0+pcols-1
   int col0, pcols;     // column chunk the solve / flux kernels are working on (scratch and part are per chunk)
-  int only_item;       // diagnostic (env RRTMG_HIP_ONLY_ITEM): >= 0 runs this position of the launch order alone (wrong results; timing)
+  RRTMG_PROFILE_FIELDS
   int *err;
   // outputs
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
@@ -581,7 +578,7 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
     pdbt = zeu > 500.0 ? sw_exp_lookup(exp_tbl, zeu) : zem2;
     const double zemm = zem1 * zem1;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(RRTMG_EXACT_REFTRA)
+#if defined(__HIP_DEVICE_COMPILE__)
     // The reference's quotients with numerator and denominator multiplied through by zem1 = exp(-k tau) (and
     // zem2 * zep2 = 1 used): ONE reciprocal instead of its three (1/zem1, 1/zem2, 1/zdenr), and the diffuse pair
     // without forming zbeta -- two reciprocals per layer operator instead of five.  Same quantities, last-place
@@ -830,7 +827,7 @@ enum { F_RUP = 0, F_RUPD, F_NCLR, F_NTOT = 2 * F_NCLR };
 struct SwLayerOpt { double ref, refd, tra, trad, dbt; };
 
 // Flux sink of the host emulation, of tests and of the device kernel: the weighted (fu, fd, cu, cd), summed over
-// each PAIR of the item's g-points, go to part[slot][k][level][column].
+// the item's g-points (pair sums first), go to part[slot][k][level][column].
 struct SwPartSink {
   double *pfu, *pfd, *pcu, *pcd;   // slot of the item's first pair
   long N, slot_stride;             // slot_stride = 4 * (nlay + 1) * ncol
@@ -997,11 +994,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   }
   // scratch slab of this (tile, item): [layer][field][lane][G] -- the G values of a lane are one 16-byte access;
   // scr points at this lane's first element, stride = lanes per row (64 on the device, 1 in the host emulation)
-#ifdef RRTMG_ABL_NOSCRATCH
-  auto SP = [&](int f, int l) -> double * { (void)l; return scr + ((long)0 * F_NTOT + f) * stride * G; };
-#else
   auto SP = [&](int f, int l) -> double * { return scr + ((long)l * F_NTOT + f) * stride * G; };
-#endif
 
   // ---- sweep 1: bottom -> top, upward adding recurrence (rrtmg_sw_vrtqdr.f90:114-140) ---------------
   double rupc[G], rupdc[G], rup[G], rupd[G];
@@ -1068,7 +1061,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
       sfu[h] = sfu[h] + zinc[g] * fu; sfd[h] = sfd[h] + zinc[g] * fd; scu[h] = scu[h] + zinc[g] * cu; scd[h] = scd[h] + zinc[g] * cd;
     }
     if constexpr (CLD && G == 4) {
-      // one slot per chunk: the two pairs' sums added here, as the flux kernel added the pair slots of the round-1 kernel
+      // one slot per chunk: the two pairs' sums added here (pair0 + pair1, the association the flux sums have had since round 1)
       sink.emit(0, lev, sfu[0] + sfu[1], sfd[0] + sfd[1], scu[0] + scu[1], scd[0] + scd[1]);
     } else if constexpr (CLD) {
       sink.emit(0, lev, sfu[0], sfd[0], scu[0], scd[0]);
@@ -1093,12 +1086,7 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
           tdn[g] = ntdn; rdnd[g] = nrdnd; tdbt[g] = ot.dbt * tdbt[g];
         }
       };
-#ifdef RRTMG_ABL_NORECOMPUTE
-#pragma unroll
-      for (int g = 0; g < G; ++g) { SwLayerOpt o; o.ref = 0.1 + 1e-3 * l; o.refd = 0.1; o.tra = 0.8; o.trad = 0.8; o.dbt = 0.7; down(g, o, o); }
-#else
       sw_layer_optics<BAND, G, CLD, LDSK>(d, T, c, col, l, down);
-#endif
     }
   }
 }
@@ -1107,13 +1095,10 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
 template <int BAND, bool CLD, bool LDSK, class Sink>
 RRTMG_HD void sw_solve_band(const SwDev &d, const SwTab &T, const double *exp_tbl, int g, int col, int ig0, double *scr, long stride, Sink &sink, const double *kb) {
   constexpr int ng = SwBandCfg<BAND>::ng;
-#ifndef RRTMG_SWC_G4
-#define RRTMG_SWC_G4 1      // cloudy tiles in chunks of 4 g-points too (sw_solve_cloudy_kernel at 2 waves/SIMD); 0: pairs at 3 waves/SIMD
-#endif
-  if constexpr ((!CLD || RRTMG_SWC_G4) && ng >= 4) {   // chunks of 4 exist in item set 0 (clear sky) only
+  if constexpr (ng >= 4) {
     if (g == 4) { sw_solve_thread<BAND, 4, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb); return; }
   }
-  if constexpr (CLD || ng % 4 != 0) sw_solve_thread<BAND, 2, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb);
+  if constexpr (ng % 4 != 0) sw_solve_thread<BAND, 2, CLD, LDSK>(d, T, exp_tbl, col, ig0, scr, stride, sink, kb);
 }
 // LDSK / kb: see sw_taug (kb = the workgroup's LDS slice of the item's band slab, or nullptr with LDSK = false)
 template <bool CLD, bool LDSK = false, class Sink>
@@ -1140,31 +1125,22 @@ RRTMG_HD void sw_solve_item(const SwDev &d, const SwTab &T, const double *exp_tb
 // spectral integration in g-point order + heating rates (rrtmg_sw_spcvrt.f90:623-627,
 // rrtmg_sw_rad.nomcica.f90:777-806)
 // one thread per (column, interface level): g-point sum in reference order
-// pairs = false: the column's tile ran the clear-sky variant, slot c holds chunk c; true: the cloudy variant, one
-// slot per pair of g-points -- the chunk sums are formed here, so the summation order is the same.
-RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, int mode, double &fu, double &fd, double &cu, double &cd) {
-  // mode 0: cloud-free tile, one slot per chunk, total-sky planes only (SwPartSink::emit_clear);
-  //      1: one slot per PAIR of g-points, four planes (the pairs item set: host emulation, RRTMG_SWC_G4=0 kernel) -- the
-  //         pairs of a chunk are added first, so that the sums associate exactly as in modes 0 and 2;
-  //      2: cloudy tile of the chunk-of-4 kernel, one slot per chunk, four planes
+// cld = false: the column's tile ran the clear-sky kernel variant, which writes the total-sky planes only
+// (SwPartSink::emit_clear); true: the cloudy variant, four planes per slot.  One slot per work item either way.
+RRTMG_HD void sw_flux_sums(const SwDev &d, const SwTab &T, int col, int lev, bool cld, double &fu, double &fd, double &cu, double &cd) {
   const int L = d.nlay, P = d.pcols;
   fu = 0.0; fd = 0.0; cu = 0.0; cd = 0.0;
   const long st = (long)(L + 1) * P, slot = 4 * st;
-  for (int c = 0; c < T.nitem[0]; ++c) {
-    const double *p = d.part + (long)(mode == 1 ? T.chunk_pair0[c] : c) * slot + (long)lev * P + (col - d.col0);
-    if (mode == 1 && T.chunk_npair[c] == 2) {
-      fu = fu + (part_load(p) + part_load(p + slot)); fd = fd + (part_load(p + st) + part_load(p + slot + st)); cu = cu + (part_load(p + 2 * st) + part_load(p + slot + 2 * st)); cd = cd + (part_load(p + 3 * st) + part_load(p + slot + 3 * st));
-    } else if (mode != 0) {
-      fu = fu + part_load(p); fd = fd + part_load(p + st); cu = cu + part_load(p + 2 * st); cd = cd + part_load(p + 3 * st);
-    } else {
-      fu = fu + part_load(p); fd = fd + part_load(p + st);
-    }
+  for (int c = 0; c < T.nitem; ++c) {
+    const double *p = d.part + (long)c * slot + (long)lev * P + (col - d.col0);
+    fu = fu + part_load(p); fd = fd + part_load(p + st);
+    if (cld) { cu = cu + part_load(p + 2 * st); cd = cd + part_load(p + 3 * st); }
   }
-  if (mode == 0) { cu = fu; cd = fd; }
+  if (!cld) { cu = fu; cd = fd; }
 }
-RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, int mode) {
+RRTMG_HD void sw_flux_level(const SwDev &d, const SwTab &T, int col, int lev, bool cld) {
   double fu, fd, cu, cd;
-  sw_flux_sums(d, T, col, lev, mode, fu, fd, cu, cd);
+  sw_flux_sums(d, T, col, lev, cld, fu, fd, cu, cd);
   const long o = (long)lev * d.ncol + col;
   d.swuflx[o] = fu; d.swdflx[o] = fd; d.swuflxc[o] = cu; d.swdflxc[o] = cd;
 }

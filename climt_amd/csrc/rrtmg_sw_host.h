@@ -81,27 +81,26 @@ inline bool build_sw_tab(TableSet &ts, SwTab &T, std::string &err) {
   T.wavenum2 = off("sw/wvn/wavenum2", true);
   T.rsrtaua = off("sw/aer/rsrtaua", true); T.rsrpiza = off("sw/aer/rsrpiza", true); T.rsrasya = off("sw/aer/rsrasya", true);
   T.heatfac = ts.heatfac;
-  // work items: set 0 = chunks of 4 (then 2) consecutive g-points of a band, set 1 = pairs; launch order heaviest first
+  // work items: chunks of 4 (then 2) consecutive g-points of a band; launch order heaviest first
   const int nspa[kSwNBand] = {9, 9, 9, 9, 1, 9, 9, 1, 9, 1, 0, 1, 9, 1};
-  for (int set = 0; set < 2; ++set) {
-    int &n = T.nitem[set];
+  {
+    int &n = T.nitem;
     n = 0;
     double cost[kSwMaxItem];
     for (int b = 0; b < kSwNBand; ++b) {
       int ig = 0;
       while (ig < T.b[b].ng) {
-        const int g = (set == 0 && T.b[b].ng - ig >= 4) ? 4 : 2;
+        const int g = (T.b[b].ng - ig >= 4) ? 4 : 2;
         if (n >= kSwMaxItem) { err = "too many work items"; return false; }
         cost[n] = (nspa[b] == 9 ? 1.0 : 0.6) + g * 1.0;
-        T.item[set][n] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);
-        if (set == 0) { T.chunk_pair0[n] = (T.b[b].gs + ig) >> 1; T.chunk_npair[n] = g >> 1; }
-        T.sched[set][n] = n;
+        T.item[n] = b | (ig << 8) | (g << 16) | ((T.b[b].gs + ig) << 20);
+        T.sched[n] = n;
         ++n;
         ig += g;
       }
     }
     for (int i = 1; i < n; ++i)   // stable insertion sort, descending cost
-      for (int j = i; j > 0 && cost[T.sched[set][j]] > cost[T.sched[set][j - 1]]; --j) { const int t = T.sched[set][j]; T.sched[set][j] = T.sched[set][j - 1]; T.sched[set][j - 1] = t; }
+      for (int j = i; j > 0 && cost[T.sched[j]] > cost[T.sched[j - 1]]; --j) { const int t = T.sched[j]; T.sched[j] = T.sched[j - 1]; T.sched[j - 1] = t; }
   }
   return err.empty();
 }

@@ -24,12 +24,12 @@ void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double
 static void emu_solve(const SwDev &d, const SwTab &T) {
   std::vector<double> scr((size_t)F_NTOT * d.nlay * 4);
   for (int col = 0; col < d.ncol; ++col) {
-    // the clear-sky variant (item set 0) for cloud-free columns, as the device picks it per tile
-    const int set = d.anycld[col] ? 1 : 0;
-    for (int i = 0; i < T.nitem[set]; ++i) {
-      const int item = T.item[set][i];
-      SwPartSink sink = sw_part_sink(d, set ? (item_iw0(item) >> 1) : i, col);
-      if (set) sw_solve_item<true>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
+    // the clear-sky variant for cloud-free columns, as the device picks it per tile
+    const bool cld = d.anycld[col] != 0;
+    for (int i = 0; i < T.nitem; ++i) {
+      const int item = T.item[i];
+      SwPartSink sink = sw_part_sink(d, i, col);
+      if (cld) sw_solve_item<true>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
       else sw_solve_item<false>(d, T, T.t + T.exp_tbl, item, col, scr.data(), 1, sink);
     }
   }

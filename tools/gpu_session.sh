@@ -43,9 +43,9 @@ except Exception as e:
         done
       done ;;
     phases)
-      # the diagnostic build with phase timers in the longwave sweeps (climt_amd/_lib/lib_phases.so: -DRRTMG_LW_PHASES)
+      # the diagnostic build with phase timers in the longwave sweeps (climt_amd/_lib/lib_profile.so: RRTMG_HIP_BUILD_FLAGS=-DRRTMG_PROFILE RRTMG_HIP_BUILD_OUT=.../lib_profile.so python climt_amd/build.py --force)
       for mode in "" "--cloudy"; do
-        RRTMG_HIP_LIB=$PWD/climt_amd/_lib/lib_phases.so timeout 200 python bench.py --no-cpu-baseline --no-extra --serial --steps 2 --warmup 1 --min-seconds 0 $mode 2>&1 | grep -A1 "lw phases" | tail -2 | tee -a $O/${R}_lw_phases.txt
+        RRTMG_HIP_LIB=$PWD/climt_amd/_lib/lib_profile.so timeout 200 python bench.py --no-cpu-baseline --no-extra --serial --steps 2 --warmup 1 --min-seconds 0 $mode 2>&1 | grep -A1 "lw phases" | tail -2 | tee -a $O/${R}_lw_phases.txt
       done ;;
     prof)
       for mode in clear cloudy; do

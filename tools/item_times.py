@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Duration of every work item of the solve kernels run ALONE (development tool, GPU): the launch-order position k of
-RRTMG_HIP_ONLY_ITEM=k is the only one that computes, so kernel_ms is that item's duration for all tiles.
-usage: tools/item_times.py [ncol=8192] [cloudy]"""
+RRTMG_HIP_ONLY_ITEM=k is the only one that computes, so kernel_ms is that item's duration for all tiles.  Needs a PROFILE
+build of the library (the product build has no such switch, climt_amd/csrc/rrtmg_profile.h):
+    RRTMG_HIP_BUILD_FLAGS=-DRRTMG_PROFILE RRTMG_HIP_BUILD_OUT=$PWD/climt_amd/_lib/lib_profile.so python climt_amd/build.py --force
+    RRTMG_HIP_LIB=$PWD/climt_amd/_lib/lib_profile.so python tools/item_times.py [ncol=8192] [cloudy]"""
 import os
 import sys
 import numpy as np
