@@ -111,6 +111,32 @@ def test_ingest_chain_reproduces_the_shipped_blob(tmp_path):
     assert set(red.files) == set(ref.files) and all(np.array_equal(red[k], ref[k]) for k in ref.files)
 
 
+@pytest.mark.skipif(not (os.path.isdir(os.path.join(REF, "climt/_lib/rrtmg_lw")) and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "librrtmg_lw_ref.so"))),
+                    reason="needs the reference checkout and oracle/_ref (build container)")
+def test_netcdf_layout_is_read_into_the_same_blob(tmp_path):
+    """The other form AER ships the longwave data in: rrtmg_lw.nc, read by the reference's rrtmg_lw_read_nc.f90.
+    tools/lw_netcdf.py takes every loader's hyperslabs (variable, target array, start, count, absorber index) from the text
+    of that file; a stand-in rrtmg_lw.nc written in this layout from today's raw tables must come back complete -- every
+    element of every raw table of rrlw_kg01..16 set -- and `pack_tables.py lw --from-nc` must pack the shipped blob from it,
+    flag cleared."""
+    from tools.lw_netcdf import parse_read_nc, read_lw_netcdf, write_lw_netcdf
+    from tools.pack_tables import read_blob
+    from tools.write_lw_k_g import raw_tables_of_blob
+    plan = parse_read_nc()
+    assert sorted(plan) == list(range(1, 17)) and sum(len(v) for v in plan.values()) == 115
+    raw = raw_tables_of_blob(read_blob(SHIPPED))
+    raw.pop((2, "refparam"), None)                 # declared by rrlw_kg02, read and used nowhere
+    nc = str(tmp_path / "rrtmg_lw.nc")
+    write_lw_netcdf(nc, raw)
+    got = read_lw_netcdf(nc)
+    assert set(got) == set(raw)
+    assert all(not np.isnan(a).any() for a in got.values())
+    assert all(np.array_equal(got[k], raw[k]) for k in raw)
+    out, fix = str(tmp_path / "from_nc.bin"), str(tmp_path / "reduced.npz")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "pack_tables.py"), "lw", "--from-nc", nc, "--out", out, "--fixture-out", fix])
+    assert open(out, "rb").read() == open(blob_with_flag(str(tmp_path / "flag0.bin"), 0), "rb").read()
+
+
 def test_longwave_cache_comparisons_execute_on_an_ingested_blob(tmp_path, monkeypatch):
     """CPU twin of tests/test_gpu_parity.py::test_longwave_cache_comparisons_execute_on_an_ingested_blob (host emulation of the
     device functions instead of the GPU): the flag alone decides whether the class refuses and whether values are compared."""

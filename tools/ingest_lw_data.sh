@@ -3,7 +3,10 @@
 # checkout this package was built against, /root/reference/.MISSING_LARGE_BLOBS:3).  Run in the build container (flang,
 # the reference checkout); nothing of the file is copied into the repository -- what ships is the packed table blob.
 #
-#   tools/ingest_lw_data.sh /path/to/rrtmg_lw_k_g.f90
+#   tools/ingest_lw_data.sh /path/to/rrtmg_lw_k_g.f90      (the Fortran data file)
+#   tools/ingest_lw_data.sh /path/to/rrtmg_lw.nc           (AER's netCDF form of the same data, read by tools/lw_netcdf.py following
+#                                                           rrtmg_lw_read_nc.f90; step 1 is skipped: the tables go into the module
+#                                                           arrays of the stub-linked library before rrtmg_lw_ini)
 #
 #   1. oracle/build_ref.sh lw   compiles the file where it lies into oracle/_ref/librrtmg_lw_ref.so (instead of the empty
 #                               loaders of oracle/lw_kg_stub.f90); oracle/_ref/lw_kdata.txt records "file <path> <sha256>"
@@ -17,13 +20,19 @@
 # (tools/write_lw_k_g.py) goes through steps 1-2 into a side directory and must reproduce the shipped blob bit for bit.
 set -euo pipefail
 ROOT="$(cd "$(dirname "${BASH_SOURCE[0]}")/.." && pwd)"
-KG="${1:?usage: tools/ingest_lw_data.sh <rrtmg_lw_k_g.f90>}"
+KG="${1:?usage: tools/ingest_lw_data.sh <rrtmg_lw_k_g.f90 | rrtmg_lw.nc>}"
 [ -f "$KG" ] || { echo "no such file: $KG" >&2; exit 1; }
 cd "$ROOT"
-RRTMG_LW_K_G="$(readlink -f "$KG")" bash oracle/build_ref.sh lw
-grep -q '^file ' oracle/_ref/lw_kdata.txt || { echo "build_ref.sh did not link the data file" >&2; exit 1; }
-python tools/pack_tables.py lw
+case "$KG" in
+  *.nc)
+    bash oracle/build_ref.sh lw                    # (stub loaders: the netCDF tables are written into the module arrays)
+    python tools/pack_tables.py lw --from-nc "$(readlink -f "$KG")" ;;
+  *)
+    RRTMG_LW_K_G="$(readlink -f "$KG")" bash oracle/build_ref.sh lw
+    grep -q '^file ' oracle/_ref/lw_kdata.txt || { echo "build_ref.sh did not link the data file" >&2; exit 1; }
+    python tools/pack_tables.py lw ;;
+esac
 python tests/golden/make_golden.py          # (regenerates every fixture; the shortwave ones come out as they are)
 python -m pytest tests -x -q -m "not gpu"
-echo "longwave tables ingested: $(cat oracle/_ref/lw_kdata.txt)"
+echo "longwave tables ingested from $KG (reference library: $(cat oracle/_ref/lw_kdata.txt))"
 echo "now run the GPU suite on an MI355X box:  python -m pytest tests -m gpu -x -q"

@@ -21,8 +21,11 @@ rrsw_aer.f90, rrsw_ref.f90, rrsw_wvn.f90, and the rrlw_* equivalents) at pack ti
                           are filled with SYNTHETIC tables (tools/synth_lw_tables.py) before
                           rrtmg_lw_ini -> "lw/meta/synthetic" = 1.
              tools/ingest_lw_data.sh <rrtmg_lw_k_g.f90> runs the whole chain for a real file.
+             --from-nc <rrtmg_lw.nc>: the data in AER's netCDF layout instead (what rrtmg_lw_read_nc.f90 reads;
+             tools/lw_netcdf.py): the raw tables are read from the file and written into the module arrays of the
+             stub-linked library before rrtmg_lw_ini, as the synthetic ones are -> "lw/meta/synthetic" = 0.
 
-  python tools/pack_tables.py [sw|lw|all] [--out <blob>] [--fixture-out <npz>]   (defaults: the shipped paths)
+  python tools/pack_tables.py [sw|lw|all] [--out <blob>] [--fixture-out <npz>] [--from-nc <rrtmg_lw.nc>]   (defaults: the shipped paths)
 
 Container: magic "RRTBL001", u32 count, then per entry
    u32 namelen, name, u32 dtype(0=f64,1=i32), u32 ndim, u32 dims[ndim] (Fortran order,
@@ -226,7 +229,7 @@ def pack_sw():
     print("SW blob:", out, os.path.getsize(out), "bytes;", len(blob.entries), "entries; reduced fixture:", len(red))
 
 
-def pack_lw(out=None, fixture_out=None):
+def pack_lw(out=None, fixture_out=None, from_nc=None):
     from oracle import ref_driver
     from oracle.ref_driver import RefLW
     from tools.synth_lw_tables import fill_reference_modules
@@ -234,7 +237,21 @@ def pack_lw(out=None, fixture_out=None):
     par = parse_params(os.path.join(libdir, "parrrtm.f90"))
     ref = RefLW()
     kdata = ref_driver.lw_kdata()
-    if kdata == "stub":
+    if from_nc:
+        if kdata != "stub":
+            raise SystemExit("pack_lw --from-nc: the reference library already has a data file compiled in (%s)" % kdata)
+        from tools.lw_netcdf import read_lw_netcdf
+        raw = read_lw_netcdf(from_nc)
+        unset = sum(int(np.isnan(a).sum()) for a in raw.values())
+        if unset:
+            raise SystemExit("pack_lw --from-nc: %d table values were not found in %s" % (unset, from_nc))
+
+        def fill(r):
+            for (b, name), arr in raw.items():
+                r.module_array("rrlw_kg%02d" % b, name, arr.shape)[...] = arr
+        ref.init(fill_tables=fill)
+        kdata = "netcdf " + from_nc
+    elif kdata == "stub":
         ref.init(fill_tables=lambda r: fill_reference_modules(r, libdir, par))
     else:
         ref.init()      # the library's own loaders (the reference's data file) fill the raw tables
@@ -266,7 +283,7 @@ def pack_lw(out=None, fixture_out=None):
 if __name__ == "__main__":
     argv = sys.argv[1:]
     opts = {}
-    for flag in ("--out", "--fixture-out"):
+    for flag in ("--out", "--fixture-out", "--from-nc"):
         if flag in argv:
             i = argv.index(flag)
             opts[flag] = argv[i + 1]
@@ -280,4 +297,4 @@ if __name__ == "__main__":
             raise SystemExit("--out / --fixture-out are implemented for 'lw' only")
         pack_sw()
     if what in ("lw", "all"):
-        pack_lw(opts.get("--out"), opts.get("--fixture-out"))
+        pack_lw(opts.get("--out"), opts.get("--fixture-out"), opts.get("--from-nc"))
