@@ -549,6 +549,16 @@ RRTMG_HD void lw_load_layer(const LwDev &d, int col, int lay, LwLayerIn &s) {
   s.indminor = (p >> 24) & 0x1f;
 }
 
+// End of one term of taumol (a group of table-row reads and the arithmetic on them): nothing is scheduled across, so that a
+// term's rows are dead before the next term's rows are requested.  Left alone the scheduler keeps ~20 rows (8 registers each
+// at G = 4) in flight to hide the LDS latency: 245 VGPRs in the clear-sky kernel, 97 spilled in the McICA one; with the fences
+// 213 / 10 spilled, the cloudy kernel 5 % faster, the clear-sky one unchanged (2 waves/SIMD either way; 168 for a third wave
+// is out of reach: the layer's 26 prep values alone are 56 registers).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define LW_FENCE __builtin_amdgcn_sched_barrier(0)
+#else
+#define LW_FENCE
+#endif
 struct LwSpec { double speccomb, specparm, fs; int js; };
 RRTMG_HD LwSpec lw_spec(double colx, double rat, double coly, double mult) {
   LwSpec r;
@@ -574,42 +584,42 @@ RRTMG_HD V<G> lw_major_lower(const KTab<G, NG> &k, int ind, const LwSpec &sp, do
     const double p = sp.fs - 1;
     const double p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-    return sp.speccomb * ((fk0 * f0) * k[ind] + (fk1 * f0) * k[ind + 1] + (fk2 * f0) * k[ind + 2] + (fk0 * f1) * k[ind + 9] +
-                          (fk1 * f1) * k[ind + 10] + (fk2 * f1) * k[ind + 11]);
+    { const V<G> r__ = sp.speccomb * ((fk0 * f0) * k[ind] + (fk1 * f0) * k[ind + 1] + (fk2 * f0) * k[ind + 2] + (fk0 * f1) * k[ind + 9] +
+                          (fk1 * f1) * k[ind + 10] + (fk2 * f1) * k[ind + 11]); LW_FENCE; return r__; }
   } else if (sp.specparm > 0.875) {
     const double p = -sp.fs;
     const double p2 = p * p, p4 = p2 * p2;
     const double fk0 = p4, fk1 = 1 - p - 2.0 * p4, fk2 = p + p4;
-    return sp.speccomb * ((fk2 * f0) * k[ind - 1] + (fk1 * f0) * k[ind] + (fk0 * f0) * k[ind + 1] + (fk2 * f1) * k[ind + 8] +
-                          (fk1 * f1) * k[ind + 9] + (fk0 * f1) * k[ind + 10]);
+    { const V<G> r__ = sp.speccomb * ((fk2 * f0) * k[ind - 1] + (fk1 * f0) * k[ind] + (fk0 * f0) * k[ind + 1] + (fk2 * f1) * k[ind + 8] +
+                          (fk1 * f1) * k[ind + 9] + (fk0 * f1) * k[ind + 10]); LW_FENCE; return r__; }
   }
-  return sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 9] +
-                        (sp.fs * f1) * k[ind + 10]);
+  { const V<G> r__ = sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 9] +
+                        (sp.fs * f1) * k[ind + 10]); LW_FENCE; return r__; }
 }
 // upper-atmosphere binary-species term (4 points, nspb = 5)
 template <int G, int NG>
 RRTMG_HD V<G> lw_major_upper(const KTab<G, NG> &k, int ind, const LwSpec &sp, double f0, double f1) {
-  return sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 5] + (sp.fs * f1) * k[ind + 6]);
+  { const V<G> r__ = sp.speccomb * (((1.0 - sp.fs) * f0) * k[ind] + (sp.fs * f0) * k[ind + 1] + ((1.0 - sp.fs) * f1) * k[ind + 5] + (sp.fs * f1) * k[ind + 6]); LW_FENCE; return r__; }
 }
 template <int G, int NG>
 RRTMG_HD V<G> lw_m4(const KTab<G, NG> &k, int i0, int i1, const LwLayerIn &s) {
-  return s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1];
+  { const V<G> r__ = s.fac00 * k[i0] + s.fac10 * k[i0 + 1] + s.fac01 * k[i1] + s.fac11 * k[i1 + 1]; LW_FENCE; return r__; }
 }
 template <int G, int NG>
 RRTMG_HD V<G> lw_tauself(const KTab<G, NG> &selfref, const LwLayerIn &s) {
   const V<G> a = selfref[s.indself - 1], b = selfref[s.indself];
-  return s.selffac * (a + s.selffrac * (b - a));
+  { const V<G> r__ = s.selffac * (a + s.selffrac * (b - a)); LW_FENCE; return r__; }
 }
 template <int G, int NG>
 RRTMG_HD V<G> lw_taufor(const KTab<G, NG> &forref, const LwLayerIn &s) {
   const V<G> a = forref[s.indfor - 1], b = forref[s.indfor];
-  return s.forfac * (a + s.forfrac * (b - a));
+  { const V<G> r__ = s.forfac * (a + s.forfrac * (b - a)); LW_FENCE; return r__; }
 }
 // minor-gas coefficient, temperature-interpolated: table (19, ng) stored [19][ng]
 template <int G, int NG>
 RRTMG_HD V<G> lw_minor1(const KTab<G, NG> &m, const LwLayerIn &s) {
   const V<G> a = m[s.indminor - 1], b = m[s.indminor];
-  return a + s.minorfrac * (b - a);
+  { const V<G> r__ = a + s.minorfrac * (b - a); LW_FENCE; return r__; }
 }
 // minor-gas coefficient, (mixture, temperature)-interpolated: table (nm, 19, ng) stored [19*nm][ng]
 template <int G, int NG>
@@ -618,13 +628,13 @@ RRTMG_HD V<G> lw_minor2(const KTab<G, NG> &m, int nm, int jm, double fm, const L
   const V<G> a0 = m[r], a1 = m[r + 1], b0 = m[r + nm], b1 = m[r + nm + 1];
   const V<G> m1 = a0 + fm * (a1 - a0);
   const V<G> m2 = b0 + fm * (b1 - b0);
-  return m1 + s.minorfrac * (m2 - m1);
+  { const V<G> r__ = m1 + s.minorfrac * (m2 - m1); LW_FENCE; return r__; }
 }
 // Planck fraction interpolated in the reference mixture: table (ng, nmix) = [nmix][ng]
 template <int G, int NG>
 RRTMG_HD V<G> lw_frac2(const KTab<G, NG> &tab, const LwSpec &pl) {
   const V<G> a = tab[pl.js - 1], b = tab[pl.js];
-  return a + pl.fs * (b - a);
+  { const V<G> r__ = a + pl.fs * (b - a); LW_FENCE; return r__; }
 }
 // "too abundant" minor-gas column adjustment: adjfac = a + (rat - a)**e  
 RRTMG_HD double lw_adjcol(double col, double coldry, double chiref, double e20, double thresh, double a, double e, double chimul) {
