@@ -950,6 +950,7 @@ RRTMG_HD void sw_layer_optics(const SwDev &d, const SwTab &T, SwThreadCtx<G> &c,
       ot.dbt = zclear * oc.dbt + zc * dbto;
     }
     consume(g, oc, ot);
+   
   }
 }
 
