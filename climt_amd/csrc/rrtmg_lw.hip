@@ -22,17 +22,18 @@ namespace rrtmg {
 // cloud flag; phase 3, cloudy tiles only: cldprop / the rtrnmr overlap factors (one wave each, sequential in the layers as
 // the reference); with McICA the cldprmc band optics stay a launch of their own (see sw_prep_fused_kernel).
 constexpr int kPrepWaves = 16;
-__global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand) {
+constexpr int kLwKeepLayers = 104;   // 104 x 3 x 64 doubles = 156 KB of the 160 KB a gfx950 workgroup can have
+static_assert(kLwKeepLayers * 3 * 64 * sizeof(double) + 1024 <= 160 * 1024, "lw_prep_fused_kernel: LDS budget of gfx950");
+__global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand, int keep_layers) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
-  // what the column scan reads back from the layer part -- [layer][coldry | h2o | lower flag][lane] -- and the per-wave cloud
-  // flags, in LDS (grids of up to kKeepLayers layers; deeper ones re-read the slab)
-  constexpr int kKeepLayers = 104;
-  static_assert(kKeepLayers * 3 * 64 * sizeof(double) + 1024 <= 160 * 1024, "lw_prep_fused_kernel: LDS budget of gfx950 (160 KB per workgroup)");
-  __shared__ double sh_keep[kKeepLayers * 3 * 64];
+  // what the column scan reads back from the layer part -- [layer][coldry | h2o | lower flag][lane] -- in DYNAMIC LDS sized by
+  // the launch for the grid's layer count (92 KB at 60 layers: a second workgroup, or a longwave solve workgroup, still fits
+  // the CU); grids deeper than kLwKeepLayers get none (keep_layers = 0) and re-read the slab
+  extern __shared__ __attribute__((aligned(16))) double sh_keep[];
   __shared__ int sh_any[kPrepWaves];
-  const bool keep = d.nlay <= kKeepLayers;
+  const bool keep = keep_layers > 0;
   bool cld = false;
   if (act)
     for (int l = w; l < d.nlay; l += kPrepWaves) {
@@ -284,7 +285,14 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     launch_interface_values(s, N, L, d.tlay, d.tsfc, d.play, d.plev, tl);
     d.tlev = tl;
   }
-  hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0);
+  {
+    // (more than 64 KB of dynamic LDS has to be allowed per kernel once; if the runtime refuses, the scan re-reads the slab)
+    static const bool big_lds = hipFuncSetAttribute((const void *)lw_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    kLwKeepLayers * 3 * 64 * (int)sizeof(double)) == hipSuccess;
+    const int keep_layers = (L <= kLwKeepLayers && (big_lds || (size_t)L * 3 * 64 * sizeof(double) <= 64 * 1024)) ? L : 0;
+    hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), s, d, T,
+                       clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0, keep_layers);
+  }
   if (clouds) {
     if (d.mcica) {
       hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);

@@ -28,7 +28,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d,
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
-  __shared__ int sh_idx[256 * 64];   // the tile's packed index words [layer][lane]: the 14 band scans of phase 2 read them here
+  extern __shared__ int sh_idx[];    // the tile's packed index words [layer][lane] (dynamic LDS, nlay x 64 ints): the 14 band scans of phase 2 read them here
   if (act)
     for (int l = w; l < d.nlay; l += kPrepWaves) sh_idx[l * 64 + lane] = sw_prep_layer(d, T, col, l);
   __syncthreads();
@@ -376,7 +376,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 
   // ---- launches ---------------------------------------------------------------------------
   const dim3 gcol(ntile), gcl(ntile, L), blk(64);
-  hipLaunchKernelGGL(sw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), 0, s, d, T, clouds && !d.mcica ? 1 : 0);
+  hipLaunchKernelGGL(sw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), s, d, T, clouds && !d.mcica ? 1 : 0);
   if (d.iaer == 6) {
     double *ta = wd("aer.tau", nl * kSwNBand), *om = wd("aer.ssa", nl * kSwNBand), *as = wd("aer.asm", nl * kSwNBand);
     if (!ok) return ctx->status;
