@@ -303,7 +303,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       } else if (a->irng == 0) {
         const uint32_t *jumps = kiss_jumps_device(ctx, 1, kLwNGpt, L, d.icld, a->permuteseed, s);
         if (!jumps) return ctx->status;
-        hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile, kLwNGpt), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
+        hipLaunchKernelGGL(kiss_mask_kernel, dim3(kLwNGpt, ntile), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
       } else {
         std::vector<double> cf(nl);
         if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }

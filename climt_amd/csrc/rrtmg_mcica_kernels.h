@@ -7,13 +7,15 @@
 
 namespace rrtmg {
 
-// kissvec sub-columns, one thread per (column, sub-column): grid (tiles, nsub).  Every thread jumps the column's
-// generator to its sub-column's first draw (kiss_jump) -- nsub times the parallelism of the column-sequential
-// reference order, same bits.
+// kissvec sub-columns, one thread per (column, sub-column): grid (nsub, tiles), the sub-column index FASTEST -- the nsub
+// blocks of a tile run back to back and re-read the tile's 64 x nlay cloud fractions from L2 (with tiles fastest the whole
+// cldfr array streamed through once per sub-column: 8 GB per launch at 131072 columns, where it no longer fits the L2s).
+// Every thread jumps the column's generator to its sub-column's first draw (kiss_jump) -- nsub times the parallelism of the
+// column-sequential reference order, same bits.
 static __global__ void __launch_bounds__(64) kiss_mask_kernel(int ncol, int nlay, int icld, const double *play, const double *cldfr,
                                                               uint64_t *mask, int nw, int *err, const uint32_t *jumps) {
-  const int col = blockIdx.x * 64 + threadIdx.x;
-  if (col < ncol) kiss_mask_jump(ncol, nlay, icld, play, cldfr, mask, nw, err, jumps, col, blockIdx.y);
+  const int col = blockIdx.y * 64 + threadIdx.x;
+  if (col < ncol) kiss_mask_jump(ncol, nlay, icld, play, cldfr, mask, nw, err, jumps, col, blockIdx.x);
 }
 
 // Jump operators of (nsub, nlay, icld, seed) on the device; rebuilt and uploaded only when the key changes.

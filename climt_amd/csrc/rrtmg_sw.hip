@@ -234,7 +234,7 @@ int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int
   const int ntile = (ncol + 63) / 64;
   const uint32_t *jumps = kiss_jumps_device(ctx, which == 0 ? 0 : 1, nsub, nlay, icld, permuteseed, s);
   if (!jumps) return ctx->status;
-  hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, icld, dp, dc, mk, nw, ctx->err_dev, jumps);
+  hipLaunchKernelGGL(kiss_mask_kernel, dim3(nsub, ntile), dim3(64), 0, s, ncol, nlay, icld, dp, dc, mk, nw, ctx->err_dev, jumps);
   hipLaunchKernelGGL(cldfmcl_from_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, nsub, mk, nw, dm);
   int herr = 0;
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, ctx->err_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -393,7 +393,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       } else if (a->irng == 0) {
         const uint32_t *jumps = kiss_jumps_device(ctx, 0, kSwNGpt, L, d.icld, a->permuteseed, s);
         if (!jumps) return ctx->status;
-        hipLaunchKernelGGL(kiss_mask_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
+        hipLaunchKernelGGL(kiss_mask_kernel, dim3(kSwNGpt, ntile), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
       } else {
         std::vector<double> cf(nl);
         if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
