@@ -173,8 +173,23 @@ def spawn_ranks(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    sys.exit(max(abs(rc) for rc in rcs))
+    # a rank that dies must not leave the others waiting in a collective until the communicator's own timeout
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if failed:
+            rc = abs(failed[0])
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=30)
+        except Exception:
+            p.kill()
+    sys.exit(rc or max(abs(p.returncode or 0) for p in procs))
 
 
 def main():

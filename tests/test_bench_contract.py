@@ -28,3 +28,15 @@ def test_help_names_the_multi_gpu_knobs():
     assert p.returncode == 0
     for flag in ("--gpus", "--gather", "--no-unpack", "--rccl-channels", "--min-seconds", "--config"):
         assert flag in p.stdout, flag
+
+
+def test_spawned_ranks_fail_fast_and_print_no_line_without_a_gpu():
+    """`--gpus 2 --share-device` starts two ranks of this script; on a box without a GPU both die at once and the parent
+    must come back promptly with their exit code and no JSON line (never a made-up n_gpus)."""
+    from climt_amd import _hip
+    if _hip.device_count() > 0:
+        import pytest
+        pytest.skip("a GPU is present: the ranks would run")
+    p = _run(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--comm", "torch", "--steps", "2"])
+    assert p.returncode != 0
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
