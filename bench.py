@@ -22,7 +22,7 @@ Prints ONE JSON line on rank 0 (see the driver contract), with
                  launches on the stream it runs on, rrtmg_hip_kernel_ms; that is also the order of the kernels' shares in
                  profiles/*_kernel_stats.txt); achieved = its ALGORITHMIC bytes per launch (SW (34L+11)*8 B, LW (56L+22)*8 B
                  per column, SURVEY.md 8d, x columns per launch) / its average launch duration; a call launches a solve
-                 kernel once per chunk of <= 32768 columns, durations are summed over the chunks and divided by their
+                 kernel once per chunk of <= 8192 columns, durations are summed over the chunks and divided by their
                  number; peak = 8 TB/s HBM3E.  roofline.kernels lists BOTH solve kernels with their durations in the timed
                  region (SW || LW: a bracket there also holds the time workgroups waited for CUs the other stream held)
                  and alone, bytes, traffic (FETCH x 2 + WRITE from the PMC passes under profiles/) and FP64 flops;

@@ -86,7 +86,7 @@ int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
 /* Duration (ms, HIP events recorded on the stream the kernel is launched on) of a solve kernel in the last completed call:
  * which = 0 -> sw_solve_all_kernel<false> (clear-sky tiles), 1 -> lw_solve_all_kernel<false,..>, 2 -> sw_solve_cloudy_kernel,
  * 3 -> lw_solve_all_kernel<true,..>.  A call launches that kernel once per column chunk (RRTMG_HIP_CHUNK_TILES tiles of 64
- * columns; one chunk up to 32768 columns); every launch has its own event bracket and the value is their SUM -- the time the
+ * columns; one chunk up to 8192 columns by default); every launch has its own event bracket and the value is their SUM -- the time the
  * kernel took for ALL the call's columns.  rrtmg_hip_kernel_launches returns the number of launches (chunks), so that
  * sum / launches is the average launch duration rocprofv3 reports for that kernel (when the GPU is not shared with another
  * stream: a bracket also contains the time its workgroups waited for compute units another stream's kernel held).

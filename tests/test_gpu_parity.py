@@ -757,8 +757,8 @@ def test_config4_shard_size_16384x60(gpu_ctx):
 
 
 def test_config5_shard_size_129600x100(gpu_ctx):
-    """BASELINE configs[4]: 1440x720x100 over 8 GPUs = 129 600 columns x 100 levels per GPU (2025 tiles: four solve
-    chunks of 512 tiles, the last one ragged)."""
+    """BASELINE configs[4]: 1440x720x100 over 8 GPUs = 129 600 columns x 100 levels per GPU (2025 tiles: sixteen solve
+    chunks of 128 tiles, the last one ragged)."""
     _shard_size_checks(gpu_ctx, 129600, 100, 4096, 42)
 
 

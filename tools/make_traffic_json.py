@@ -4,12 +4,12 @@
 
   traffic  = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- FETCH_SIZE doubled per the gfx950 correction of
              MI355X_MICROARCH.md (HBM section: 128-B requests tallied at 64 B); memory-side requests of the L2s, i.e. HBM plus
-             Infinity-Cache hits.  The 131072-column passes (4 solve chunks of 32768 columns per call, prep slab 0.9-1.6 GB,
+             Infinity-Cache hits.  The 131072-column passes (solve chunks of RRTMG_HIP_CHUNK_TILES x 64 columns per call, prep slab 0.9-1.6 GB,
              scratch 9-14 GB per chunk: far beyond the 256 MB Infinity Cache) give the same bytes per column as the
              8192-column ones, so the traffic is HBM traffic.
   flops    = (2 x FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions x 64 lanes per launch.
 Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 columns the value is per
-launch of one 32768-column chunk.
+launch of one column chunk.
   "step|<columns>|<levels>|<clear|cloudy>" = the same counters summed over EVERY kernel of one LW+SW step (preparation,
              cloud optics / sub-column masks, both solve variants, flux + heating): sum over kernels of (average per dispatch x
              dispatches) / steps, steps = dispatches of sw_prep_fused_kernel (one per step); "step_kernels|..." lists the terms.
