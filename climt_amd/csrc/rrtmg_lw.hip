@@ -1,12 +1,12 @@
 // rrtmg_lw.hip -- longwave kernels and launch sequence (gfx950).
 //
 // Launch sequence of one rrtmg_hip_lw_fluxes call (all on the context's longwave stream):
-//   lw_prep_fused_kernel <<<tiles, 16 waves>>>  inatm + setcoef per (column, layer), then the column part (laytrop, precipitable
-//                        water -> secdiff, tile cloud flag) on what the layer part left in LDS; non-McICA cloudy tiles: cldprop
-//                        and the rtrnmr overlap factors
-//   lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
-//   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA)
-//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles):
+//   kiss_mask_kernel / mask upload + lw_anymask_kernel (McICA, whole grid)
+//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles), so that a chunk's rows are still cached when its solve reads them:
+//     lw_prep_fused_kernel <<<tiles, 16 waves>>>  inatm + setcoef per (column, layer), then the column part (laytrop,
+//                          precipitable water -> secdiff, tile cloud flag) on what the layer part left in LDS; non-McICA cloudy
+//                          tiles: cldprop and the rtrnmr overlap factors
+//     lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
 //     lw_solve_all_kernel  one launch per variant (cloud-free / cloudy tiles): wavefront = tile(64 columns) x work item (4|2
 //                          g-points of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
 //     lw_fluxheat_kernel   <<<(tiles, levels/15), 16 waves>>>  band / g-point integration per interface + heating rates
@@ -24,8 +24,9 @@ namespace rrtmg {
 constexpr int kPrepWaves = 16;
 constexpr int kLwKeepLayers = 104;   // 104 x 3 x 64 doubles = 156 KB of the 160 KB a gfx950 workgroup can have
 static_assert(kLwKeepLayers * 3 * 64 * sizeof(double) + 1024 <= 160 * 1024, "lw_prep_fused_kernel: LDS budget of gfx950");
-__global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand, int keep_layers) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+__global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d, LwTab T, int clouds, int maxrand, int keep_layers, int tile0) {
+  const int tile = tile0 + blockIdx.x;   // (launched per column chunk, see sw_prep_fused_kernel)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = tile * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
   // what the column scan reads back from the layer part -- [layer][coldry | h2o | lower flag][lane] -- in DYNAMIC LDS sized by
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
     if (lane == 0) {
       int any = 0;
       for (int k = 0; k < kPrepWaves; ++k) any |= sh_any[k];
-      d.tile_cld[blockIdx.x] = any; sh_cld = any;
+      d.tile_cld[tile] = any; sh_cld = any;
     }
   }
   if (!clouds) return;
@@ -60,9 +61,10 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
   if (w == kPrepWaves - 1 && maxrand) lw_mr_column(d, col);
 }
 
-__global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T) {
-  if (!d.tile_cld[blockIdx.x]) return;
-  const int col = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64) lw_cloudmc_kernel(LwDev d, LwTab T, int tile0) {
+  const int tile = tile0 + blockIdx.x;
+  if (!d.tile_cld[tile]) return;
+  const int col = tile * 64 + threadIdx.x;
   if (col < d.ncol) lw_cloudmc_layer(d, T, col, blockIdx.y);
 }
 __global__ void __launch_bounds__(64) lw_anymask_kernel(LwDev d) {
@@ -276,7 +278,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     RRTMG_HIP_CHECK(ctx, hipMemsetAsync(d.err, 0, sizeof(int), s));
   }   // deferred: the flag accumulates (atomicMax) until rrtmg_hip_synchronize collects and clears it
 
-  const dim3 gcol(ntile), gcl(ntile, L), blk(64);
+  const dim3 gcol(ntile), blk(64);
   if (!d.tlev) {
     // no interface temperatures given: log-pressure interpolation of the layer temperatures on the device, as climt's
     // host does before the call when calculate_interface_temperature is set (lw/component.py:378-384, util.py:89-142)
@@ -285,17 +287,12 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     launch_interface_values(s, N, L, d.tlay, d.tsfc, d.play, d.plev, tl);
     d.tlev = tl;
   }
-  {
-    // (more than 64 KB of dynamic LDS has to be allowed per kernel once; if the runtime refuses, the scan re-reads the slab)
-    static const bool big_lds = hipFuncSetAttribute((const void *)lw_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    kLwKeepLayers * 3 * 64 * (int)sizeof(double)) == hipSuccess;
-    const int keep_layers = (L <= kLwKeepLayers && (big_lds || (size_t)L * 3 * 64 * sizeof(double) <= 64 * 1024)) ? L : 0;
-    hipLaunchKernelGGL(lw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), s, d, T,
-                       clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0, keep_layers);
-  }
+  // (more than 64 KB of dynamic LDS has to be allowed per kernel once; if the runtime refuses, the scan re-reads the slab)
+  static const bool big_lds = hipFuncSetAttribute((const void *)lw_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  kLwKeepLayers * 3 * 64 * (int)sizeof(double)) == hipSuccess;
+  const int keep_layers = (L <= kLwKeepLayers && (big_lds || (size_t)L * 3 * 64 * sizeof(double) <= 64 * 1024)) ? L : 0;
   if (clouds) {
     if (d.mcica) {
-      hipLaunchKernelGGL(lw_cloudmc_kernel, gcl, blk, 0, s, d, T);
       if (a->cldfmcl) {
         const double *cm = in(a->cldfmcl, nl * kLwNGpt, "cldfmcl", true);
         if (!ok) return ctx->status;
@@ -316,10 +313,13 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
     }
   }
-  // solve + band integration, one column chunk at a time (see sw_fluxes_impl)
+  // preparation, solve and band integration, one column chunk at a time (see sw_fluxes_impl)
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
+    hipLaunchKernelGGL(lw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), s, d, T,
+                       clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0, keep_layers, t0);
+    if (clouds && d.mcica) hipLaunchKernelGGL(lw_cloudmc_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const int ci = t0 / ctile;

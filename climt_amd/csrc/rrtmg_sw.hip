@@ -1,13 +1,13 @@
 // rrtmg_sw.hip -- shortwave kernels and launch sequence (gfx950).
 //
 // Launch sequence of one rrtmg_hip_sw_fluxes call (all on the context's shortwave stream):
-//   sw_prep_fused_kernel <<<tiles, 16 waves>>>   inatm_sw + setcoef_sw per (column, layer), then the column part from the index
-//                        words in LDS (laytrop, cloud flag, solar-source layer per band); non-McICA cloudy tiles: the band cloud
-//                        optics
 //   sw_aer_kernel       (iaer == 6)              ECMWF aerosol mixing per (column, layer)
-//   sw_cloud_kernel     (McICA)                  band cloud optics per (column, layer)
 //   kiss_mask_kernel / mask upload (McICA)       sub-column cloud mask
-//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles):
+//   per column chunk (<= RRTMG_HIP_CHUNK_TILES tiles), so that a chunk's rows are still cached when its solve reads them:
+//     sw_prep_fused_kernel <<<tiles, 16 waves>>>  inatm_sw + setcoef_sw per (column, layer), then the column part from the
+//                         index words in LDS (laytrop, cloud flag, solar-source layer per band); non-McICA cloudy tiles: the
+//                         band cloud optics
+//     sw_cloud_kernel     (McICA)                 band cloud optics per (column, layer)
 //     sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel (cloudy tiles): wavefront = tile(64 columns) x work
 //                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS
 //     sw_fluxheat_kernel  <<<(tiles, levels/15), 16 waves>>>  g-point sum per interface + heating rates
@@ -24,8 +24,9 @@ namespace rrtmg {
 // cloudy, the optics stay a launch of their own over (tile, layer): one workgroup per tile was measured 5 % slower on the
 // whole McICA step).  Same per-thread functions, same results.
 constexpr int kPrepWaves = 16;
-__global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d, SwTab T, int clouds) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = blockIdx.x * 64 + lane;
+__global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d, SwTab T, int clouds, int tile0) {
+  const int tile = tile0 + blockIdx.x;   // (launched per column chunk, right before the chunk's solve: its rows are still cached)
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, col = tile * 64 + lane;
   const bool act = col < d.ncol;
   __shared__ int sh_cld;
   extern __shared__ int sh_idx[];    // the tile's packed index words [layer][lane] (dynamic LDS, nlay x 64 ints): the 14 band scans of phase 2 read them here
@@ -36,7 +37,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d,
     for (int b = w; b < kSwNBand; b += kPrepWaves) sw_prep_column(d, T, col, b, b + 1, sh_idx + lane, 64);
   if (w == 0) {
     const unsigned long long any = __ballot(act && d.anycld[col] != 0);
-    if (lane == 0) { d.tile_cld[blockIdx.x] = any != 0ull; sh_cld = any != 0ull; }
+    if (lane == 0) { d.tile_cld[tile] = any != 0ull; sh_cld = any != 0ull; }
   }
   if (!clouds) return;
   __syncthreads();
@@ -44,9 +45,10 @@ __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d,
   for (int l = w; l < d.nlay; l += kPrepWaves) sw_cloud_layer(d, T, col, l);
 }
 
-__global__ void __launch_bounds__(64) sw_cloud_kernel(SwDev d, SwTab T) {
-  if (!d.tile_cld[blockIdx.x]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
-  const int col = blockIdx.x * 64 + threadIdx.x;
+__global__ void __launch_bounds__(64) sw_cloud_kernel(SwDev d, SwTab T, int tile0) {
+  const int tile = tile0 + blockIdx.x;
+  if (!d.tile_cld[tile]) return;   // cloud-free tile: the clear-sky solve variant never reads the cloud optics
+  const int col = tile * 64 + threadIdx.x;
   const int lay = blockIdx.y;
   if (col < d.ncol) sw_cloud_layer(d, T, col, lay);
 }
@@ -375,8 +377,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   }   // deferred: the flag accumulates (atomicMax) until rrtmg_hip_synchronize collects and clears it
 
   // ---- launches ---------------------------------------------------------------------------
-  const dim3 gcol(ntile), gcl(ntile, L), blk(64);
-  hipLaunchKernelGGL(sw_prep_fused_kernel, gcol, dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), s, d, T, clouds && !d.mcica ? 1 : 0);
+  const dim3 gcl(ntile, L), blk(64);
   if (d.iaer == 6) {
     double *ta = wd("aer.tau", nl * kSwNBand), *om = wd("aer.ssa", nl * kSwNBand), *as = wd("aer.asm", nl * kSwNBand);
     if (!ok) return ctx->status;
@@ -384,7 +385,6 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     d.tauaer = ta; d.ssaaer = om; d.asmaer = as;
   }
   if (clouds) {
-    if (d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, gcl, blk, 0, s, d, T);
     if (d.mcica) {
       if (a->cldfmcl) {
         const double *cm = in(a->cldfmcl, nl * kSwNGpt, "cldfmcl", true);
@@ -405,11 +405,14 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       }
     }
   }
-  // solve + spectral integration, one column chunk at a time (the event pairs bracket the two solve launches of the LAST
-  // chunk, one launch each; with a single chunk -- up to chunk_tiles * 64 columns -- that is the whole solve)
+  // preparation, solve and spectral integration, one column chunk at a time: the chunk's prep rows (58 MB at 8192 columns x
+  // 60 layers) are read by its 32 work items while still in the L2s / the Infinity Cache, not streamed back from HBM after
+  // the preparation of the whole grid (every solve launch of every chunk has its own event pair)
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
+    hipLaunchKernelGGL(sw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), s, d, T, clouds && !d.mcica ? 1 : 0, t0);
+    if (clouds && d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
     const int ci = t0 / ctile;

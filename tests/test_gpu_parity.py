@@ -372,19 +372,20 @@ def test_argument_errors(gpu_ctx):
 
 
 def test_column_chunks_are_invisible(gpu_ctx, monkeypatch):
-    """The solve + spectral-integration stages run over chunks of at most RRTMG_HIP_CHUNK_TILES 64-column tiles (bounded
-    scratch): 5 ragged chunks give bitwise the results of one."""
+    """The preparation, solve and spectral-integration stages run over chunks of at most RRTMG_HIP_CHUNK_TILES 64-column
+    tiles (bounded scratch, cached prep rows): 5 ragged chunks give bitwise the results of one."""
     from climt_amd._lib import Context
     from climt_amd.synthetic import make_columns
     from helpers import CONSTANTS, CPDAIR
     c = make_columns(600, 40, cloudy=True, seed=77); c.update(BASE); c.update(irng=0, permuteseed=5)
     c["cldfr"][:, 128:320] = 0.0; c["cliqwp"][:, 128:320] = 0.0; c["cicewp"][:, 128:320] = 0.0   # some clear tiles
-    ref_sw, ref_lw = gpu_ctx.sw_fluxes(c, mcica=True), gpu_ctx.lw_fluxes(c, mcica=True)
+    ref = {m: (gpu_ctx.sw_fluxes(c, mcica=m), gpu_ctx.lw_fluxes(c, mcica=m)) for m in (True, False)}
     monkeypatch.setenv("RRTMG_HIP_CHUNK_TILES", "2")
     small = Context(0); small.set_constants(**CONSTANTS); small.sw_init(CPDAIR); small.lw_init(CPDAIR)
-    sw, lw = small.sw_fluxes(c, mcica=True), small.lw_fluxes(c, mcica=True)
-    assert all(np.array_equal(sw[k], ref_sw[k]) for k in sw)
-    assert all(np.array_equal(lw[k], ref_lw[k]) for k in lw)
+    for m in (True, False):   # the preparation launches are per chunk too, with and without McICA
+        sw, lw = small.sw_fluxes(c, mcica=m), small.lw_fluxes(c, mcica=m)
+        assert all(np.array_equal(sw[k], ref[m][0][k]) for k in sw), m
+        assert all(np.array_equal(lw[k], ref[m][1][k]) for k in lw), m
 
 
 def test_mcica_mask_matches_reference_generator(gpu_ctx):
