@@ -85,13 +85,14 @@ except ImportError:
         u = (u or "").strip()
         return _UNIT_ALIASES.get(u, u)
 
-    def convert_units(values, src, dst):
+    def convert_units(values, src, dst, scale=None):
+        """`scale(values, factor)`: forms the product instead of `values * factor` when given (a component's input staging)."""
         s, d = _canon(src), _canon(dst)
         if s == d:
             return values
         if s in _TO_BASE and d in _TO_BASE and _TO_BASE[s][0] == _TO_BASE[d][0]:
             f = _TO_BASE[s][1] / _TO_BASE[d][1]
-            return values * f
+            return scale(values, f) if scale is not None else values * f
         raise ValueError("cannot convert units %r -> %r" % (src, dst))
 
     def initialize_numpy_arrays_with_properties(output_properties, raw_input_state, input_properties, dtype=np.float64):
@@ -120,6 +121,7 @@ except ImportError:
         # -- state -> raw arrays ------------------------------------------------------------
         def _extract(self, state):
             raw = {"time": state.get("time")}
+            staging = getattr(self, "_input_staging", None)   # see climt_amd/rrtmg/common.py: the products form in the background
             wild_names, wild_shape = None, None
             self._dim_lengths = {}
             for name, prop in self.input_properties.items():
@@ -128,7 +130,8 @@ except ImportError:
                 da = state[name]
                 values, dims = np.asarray(da.values), tuple(da.dims)
                 if values.dtype.kind in "fiub":     # numeric; string quantities (area_type) pass through
-                    values = convert_units(values.astype(np.float64, copy=False), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
+                    scale = (lambda v, f, name=name: staging.scaled(name, v, f)) if staging is not None and values.ndim >= 2 else None
+                    values = convert_units(values.astype(np.float64, copy=False), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")), scale=scale)
                 want = list(prop["dims"])
                 named = [d for d in want if d != "*"]
                 for d in named:
@@ -149,6 +152,8 @@ except ImportError:
                 order = []
                 for d in want:
                     order.extend([dims.index(w) for w in (wild if d == "*" else [d])])
+                if staging is not None and order != list(range(len(order))):
+                    staging.wait()   # the re-ordering below reads the product
                 arr = np.transpose(values, order) if order else values
                 shape = []
                 for d in want:
@@ -160,6 +165,8 @@ except ImportError:
                 raw[name] = np.ascontiguousarray(arr.reshape(shape)) if want else arr
             self._wild_names = wild_names or []
             self._wild_shape = wild_shape or []
+            if staging is not None:
+                staging.wait()
             return raw
 
         def _wrap(self, arrays, properties):

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <mutex>
 
+#include <atomic>
+
 #include "rrtmg_ctx.h"
 
 namespace rrtmg {
@@ -77,6 +79,34 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
   work(0);
   for (auto &x : th) x.join();
   return RRTMG_OK;
+}
+
+// true when every one of the n doubles at p is +0.0 (all bits clear).  The head is checked first (an array with data in it
+// is recognised in microseconds); an array that passes that is scanned in slices on a few host threads, each giving up as
+// soon as any of them has found a set bit.
+bool host_all_zero(const double *p, size_t n) {
+  const uint64_t *q = (const uint64_t *)p;
+  const size_t head = n < 4096 ? n : 4096;
+  for (size_t i = 0; i < head; ++i) if (q[i]) return false;
+  if (n == head) return true;
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
+  if (n < ((size_t)1 << 19)) nt = 1;
+  std::atomic<bool> found(false);
+  auto work = [&](unsigned t) {
+    const size_t per = (n + nt - 1) / nt, lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
+    for (size_t i = lo; i < hi && !found.load(std::memory_order_relaxed); i += 4096) {
+      const size_t e = i + 4096 < hi ? i + 4096 : hi;
+      uint64_t acc = 0;
+      for (size_t j = i; j < e; ++j) acc |= q[j];
+      if (acc) found.store(true, std::memory_order_relaxed);
+    }
+  };
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+  work(0);
+  for (auto &x : th) x.join();
+  return !found.load();
 }
 
 std::string default_blob_path(const char *which) {

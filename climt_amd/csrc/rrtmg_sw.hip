@@ -299,12 +299,13 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 
   // ---- inputs -----------------------------------------------------------------------------
   bool ok = true;
-  auto in = [&](const double *p, size_t n, const char *name, bool required) -> const double * {
+  auto in = [&](const double *p, size_t n, const char *name, bool required, bool zeros_are_absent = false) -> const double * {
     if (!p) {
       if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
       return nullptr;
     }
     if (a->memspace == 1) return p;
+    if (zeros_are_absent && !required && n >= (size_t)1 << 16 && host_all_zero(p, n)) return nullptr;   // (rrtmg_ctx.h: nothing to add, nothing to send)
     double *dp = (double *)ctx->buf(std::string("sw.in.") + name, n * sizeof(double));
     if (!dp) { ok = false; return nullptr; }
     if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
@@ -320,7 +321,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds) {
     d.cldfr = in(a->cldfr, nl, "cldfr", true);
     const bool optics = (d.inflag == 0);
-    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
+    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics, true);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
     // single-scattering albedo / asymmetry / forward fraction are read only where the optics are given directly -- under
     // inflag 2 they would multiply an optical depth below cldmin = 1e-20 at most -- so host copies are not uploaded then
     const bool up = optics || a->memspace == 1;

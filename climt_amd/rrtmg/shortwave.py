@@ -7,8 +7,8 @@ import logging
 import numpy as np
 
 from .._sympl_compat import TendencyComponent, get_constant
-from .._util import ensure_contiguous_state, mass_to_volume_mixing_ratio
-from .common import (OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
+from .._util import ensure_contiguous_state
+from .common import (InputStaging, OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
                      rrtmg_cloud_overlap_method_dict, rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
 
@@ -119,6 +119,7 @@ class RRTMGShortwave(TendencyComponent):
         self._Cpd = get_constant("heat_capacity_of_dry_air_at_constant_pressure", "J/kg/K")
         self._ctx = make_context(device)
         self._pool = OutputPool()
+        self._input_staging = InputStaging()
         # the reference re-runs rrtmg_sw_ini on every McICA call (sw/component.py:547-560); the tables do
         # not depend on the call, so they are built once here
         self._ctx.sw_init(self._Cpd)
@@ -135,7 +136,8 @@ class RRTMGShortwave(TendencyComponent):
     @ensure_contiguous_state
     def array_call(self, state):
         """Shortwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
-        Q = mass_to_volume_mixing_ratio(state["specific_humidity"], 18.02)
+        # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02, formed in four pieces in the background (common.InputStaging)
+        Q = self._input_staging.scaled("h2ovmr", state["specific_humidity"], 28.964, 18.02, pieces=4)
         assert state["air_pressure"].shape[0] + 1 == state["air_pressure_on_interface_levels"].shape[0]
         # (the reference also interpolates interface temperatures here, sw/component.py:492-496; RRTMG_SW never reads them)
         Tint = None
@@ -175,6 +177,7 @@ class RRTMGShortwave(TendencyComponent):
             swhr=tendencies["air_temperature"], swuflxc=diagnostics["upwelling_shortwave_flux_in_air_assuming_clear_sky"],
             swdflxc=diagnostics["downwelling_shortwave_flux_in_air_assuming_clear_sky"],
             swhrc=diagnostics["air_temperature_tendency_from_shortwave_assuming_clear_sky"])
+        self._input_staging.wait()
         self._ctx.sw_fluxes(inp, mcica=self._mcica, out=out)
         diagnostics["air_temperature_tendency_from_shortwave"][:] = tendencies["air_temperature"]
         return tendencies, diagnostics

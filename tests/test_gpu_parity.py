@@ -248,6 +248,46 @@ def test_device_pointer_path_equals_host_pointer_path(gpu_ctx):
     assert gpu_ctx.kernel_ms("sw") > 0.0
 
 
+def test_all_zero_band_arrays_are_not_sent_and_count_as_zeros(gpu_ctx):
+    """Host arrays that are entirely +0.0 where zeros mean "nothing to add" (band optical depths of clouds / aerosols, CFCs) are
+    recognised on the host and not uploaded; the device-pointer path uploads whatever it is given.  Both must give the same
+    bits -- with all-zero arrays, and with ONE non-zero at the very end of an array (found by the threaded scan, not the head)."""
+    from climt_amd import _hip
+    from climt_amd._lib import LW_OUT, SW_OUT
+    from climt_amd.synthetic import make_columns
+    N, L = 256, 40
+    c = make_columns(N, L, cloudy=True, seed=11); c.update(BASE); c.pop("lat", None)
+    c["cldfr"] = (c["cldfr"] > 0.3).astype(float)   # (the shortwave without McICA takes overcast or clear layers only)
+
+    def both(which, extra):
+        inp = dict(c); inp.update(extra)
+        fluxes, outs = (gpu_ctx.sw_fluxes, SW_OUT) if which == "sw" else (gpu_ctx.lw_fluxes, LW_OUT)
+        host = fluxes(inp)
+        dev = {k: _hip.DeviceArray.from_host(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        args = {k: v.ptr for k, v in dev.items()}
+        args.update({k: v for k, v in inp.items() if not isinstance(v, np.ndarray)}); args.update(ncol=N, nlay=L)
+        out = {k: _hip.DeviceArray((L + lev, N)) for k, lev in outs}
+        fluxes(args, out={k: v.ptr for k, v in out.items()}, memspace=1)
+        assert all(np.array_equal(host[k], out[k].download()) for k in host), (which, sorted(extra))
+        return host
+
+    zl = dict(tauaer=np.zeros((16, L, N)), taucld=np.zeros((L, N, 16)), cfc11=np.zeros((L, N)), ccl4=np.zeros((L, N)))
+    base = both("lw", zl)
+    absent = gpu_ctx.lw_fluxes(dict(c, cfc11=zl["cfc11"], ccl4=zl["ccl4"]))     # no tauaer / taucld given at all
+    assert all(np.array_equal(base[k], v) for k, v in absent.items())
+    for name in ("tauaer", "taucld", "cfc11"):
+        one = {k: v.copy() for k, v in zl.items()}
+        one[name].reshape(-1)[-1] = 0.4 if name != "cfc11" else 1e-9
+        r = both("lw", one)
+        if name != "taucld":   # (the last layer / column of taucld only counts where the column has a cloud there)
+            assert not np.array_equal(r["uflx"], base["uflx"]), name
+    zs = dict(taucld=np.zeros((L, N, 14)))
+    sbase = both("sw", zs)
+    assert all(np.array_equal(sbase[k], v) for k, v in gpu_ctx.sw_fluxes(c).items())
+    one = dict(taucld=zs["taucld"].copy()); one["taucld"].reshape(-1)[-1] = 0.4
+    both("sw", one)
+
+
 def test_error_status_instead_of_stop(gpu_ctx):
     from climt_amd._lib import RRTMGError
     c, _, _ = load_ref_case("overcast_L60")
@@ -379,11 +419,13 @@ def test_column_chunks_are_invisible(gpu_ctx, monkeypatch):
     from helpers import CONSTANTS, CPDAIR
     c = make_columns(600, 40, cloudy=True, seed=77); c.update(BASE); c.update(irng=0, permuteseed=5)
     c["cldfr"][:, 128:320] = 0.0; c["cliqwp"][:, 128:320] = 0.0; c["cicewp"][:, 128:320] = 0.0   # some clear tiles
-    ref = {m: (gpu_ctx.sw_fluxes(c, mcica=m), gpu_ctx.lw_fluxes(c, mcica=m)) for m in (True, False)}
+    # (without McICA the shortwave takes overcast or clear layers only)
+    case = {True: c, False: dict(c, cldfr=(c["cldfr"] > 0.3).astype(float))}
+    ref = {m: (gpu_ctx.sw_fluxes(case[m], mcica=m), gpu_ctx.lw_fluxes(case[m], mcica=m)) for m in (True, False)}
     monkeypatch.setenv("RRTMG_HIP_CHUNK_TILES", "2")
     small = Context(0); small.set_constants(**CONSTANTS); small.sw_init(CPDAIR); small.lw_init(CPDAIR)
     for m in (True, False):   # the preparation launches are per chunk too, with and without McICA
-        sw, lw = small.sw_fluxes(c, mcica=m), small.lw_fluxes(c, mcica=m)
+        sw, lw = small.sw_fluxes(case[m], mcica=m), small.lw_fluxes(case[m], mcica=m)
         assert all(np.array_equal(sw[k], ref[m][0][k]) for k in sw), m
         assert all(np.array_equal(lw[k], ref[m][1][k]) for k in lw), m
 
