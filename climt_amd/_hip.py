@@ -47,19 +47,25 @@ def synchronize():
     _ck(lib().hipDeviceSynchronize(), "hipDeviceSynchronize")
 
 
-def pinned_empty(shape, dtype=np.float64):
-    """A page-locked host array (hipHostMalloc): copies to and from the device run at the link rate and asynchronously,
-    and its pages exist (no first-touch faults).  Freed when the array and every view of it are gone."""
+def pinned_buffer(nbytes):
+    """nbytes of page-locked host memory (hipHostMalloc) as a ctypes byte array: copies to and from the device run at the link
+    rate and asynchronously, and its pages exist (no first-touch faults).  Freed when the object and every array made from it
+    (np.frombuffer) are gone."""
     import weakref
-    shape = tuple(int(s) for s in np.atleast_1d(shape))
-    dt = np.dtype(dtype)
-    nbytes = max(int(np.prod(shape)) * dt.itemsize, 8)
+    nbytes = max(int(nbytes), 8)
     p = C.c_void_p()
     _ck(lib().hipHostMalloc(C.byref(p), C.c_size_t(nbytes), C.c_uint(0)), "hipHostMalloc")
     buf = (C.c_char * nbytes).from_address(p.value)
-    root = np.frombuffer(buf, dtype=dt, count=int(np.prod(shape)))
-    weakref.finalize(root, lib().hipHostFree, C.c_void_p(p.value))
-    return root.reshape(shape)
+    weakref.finalize(buf, lib().hipHostFree, C.c_void_p(p.value))
+    return buf
+
+
+def pinned_empty(shape, dtype=np.float64):
+    """A page-locked host array (pinned_buffer) of the given shape."""
+    shape = tuple(int(s) for s in np.atleast_1d(shape))
+    dt = np.dtype(dtype)
+    count = int(np.prod(shape))
+    return np.frombuffer(pinned_buffer(count * dt.itemsize), dtype=dt, count=count).reshape(shape)
 
 
 class DeviceArray:

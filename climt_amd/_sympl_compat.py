@@ -119,19 +119,19 @@ except ImportError:
             self.name = name or self.__class__.__name__.lower()
 
         # -- state -> raw arrays ------------------------------------------------------------
-        def _extract(self, state):
-            raw = {"time": state.get("time")}
-            staging = getattr(self, "_input_staging", None)   # see climt_amd/rrtmg/common.py: the products form in the background
+        def _plan(self, state):
+            """How each input gets from the state to array_call, worked out once per state STRUCTURE (dims, units, shapes):
+            per input (factor or None, axis order or None, shape), plus the wildcard dims and the named dim lengths."""
+            steps, lengths = [], {}
             wild_names, wild_shape = None, None
-            self._dim_lengths = {}
             for name, prop in self.input_properties.items():
-                if name not in state:
-                    raise KeyError("state is missing input quantity %r" % name)
                 da = state[name]
-                values, dims = np.asarray(da.values), tuple(da.dims)
-                if values.dtype.kind in "fiub":     # numeric; string quantities (area_type) pass through
-                    scale = (lambda v, f, name=name: staging.scaled(name, v, f)) if staging is not None and values.ndim >= 2 else None
-                    values = convert_units(values.astype(np.float64, copy=False), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")), scale=scale)
+                shape_in, dims = np.shape(da.values), tuple(da.dims)
+                numeric = np.asarray(da.values).dtype.kind in "fiub"     # string quantities (area_type) pass through
+                factor = None
+                if numeric:
+                    probe = convert_units(np.ones(()), da.attrs.get("units", ""), prop.get("units", da.attrs.get("units", "")))
+                    factor = None if float(probe) == 1.0 else float(probe)
                 want = list(prop["dims"])
                 named = [d for d in want if d != "*"]
                 for d in named:
@@ -141,7 +141,7 @@ except ImportError:
                 if "*" in want:
                     if wild_names is None:
                         wild_names = wild
-                        wild_shape = [values.shape[dims.index(d)] for d in wild]
+                        wild_shape = [shape_in[dims.index(d)] for d in wild]
                     elif wild and wild != wild_names:
                         # same wildcard dims in another order are transposed to the first ordering
                         if sorted(wild) != sorted(wild_names):
@@ -152,19 +152,43 @@ except ImportError:
                 order = []
                 for d in want:
                     order.extend([dims.index(w) for w in (wild if d == "*" else [d])])
-                if staging is not None and order != list(range(len(order))):
-                    staging.wait()   # the re-ordering below reads the product
-                arr = np.transpose(values, order) if order else values
                 shape = []
                 for d in want:
                     if d == "*":
-                        shape.append(int(np.prod([values.shape[dims.index(w)] for w in wild])) if wild else 1)
+                        shape.append(int(np.prod([shape_in[dims.index(w)] for w in wild])) if wild else 1)
                     else:
-                        shape.append(values.shape[dims.index(d)])
-                        self._dim_lengths[d] = shape[-1]
-                raw[name] = np.ascontiguousarray(arr.reshape(shape)) if want else arr
-            self._wild_names = wild_names or []
-            self._wild_shape = wild_shape or []
+                        shape.append(shape_in[dims.index(d)])
+                        lengths[d] = shape[-1]
+                identity = order == list(range(len(order)))
+                steps.append((name, numeric, factor, None if identity else order, tuple(shape) if want else None))
+            return steps, lengths, wild_names or [], wild_shape or []
+
+        def _extract(self, state):
+            raw = {"time": state.get("time")}
+            staging = getattr(self, "_input_staging", None)   # see climt_amd/rrtmg/common.py: the products form in the background
+            try:
+                sig = tuple((tuple(state[n].dims), state[n].attrs.get("units", ""), np.shape(state[n].values)) for n in self.input_properties)
+            except KeyError as e:
+                raise KeyError("state is missing input quantity %r" % e.args[0])
+            plans = self.__dict__.setdefault("_plans", {})
+            plan = plans.get(sig)
+            if plan is None:
+                plan = plans[sig] = self._plan(state)
+            steps, self._dim_lengths, self._wild_names, self._wild_shape = plan
+            for name, numeric, factor, order, shape in steps:
+                values = np.asarray(state[name].values)
+                if numeric:
+                    values = values.astype(np.float64, copy=False)
+                    if factor is not None:
+                        if staging is not None and values.ndim >= 2:
+                            values = staging.scaled(name, values, factor)
+                            if order is not None:
+                                staging.wait()   # the re-ordering below reads the product
+                        else:
+                            values = values * factor
+                if order is not None:
+                    values = np.transpose(values, order)
+                raw[name] = np.ascontiguousarray(values.reshape(shape)) if shape is not None else values
             if staging is not None:
                 staging.wait()
             return raw

@@ -45,8 +45,16 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
 }
 
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host) {
+  // A destination that is page-locked memory the runtime knows (hipHostMalloc / hipHostRegister: the components' output pool
+  // hands such arrays out) takes its copy directly; the others go through the staging buffer.
+  bool direct[16];
   size_t total = 0;
-  for (int i = 0; i < count; ++i) total += o[i].n * sizeof(double);
+  for (int i = 0; i < count; ++i) {
+    hipPointerAttribute_t at;
+    direct[i] = i < 16 && hipPointerGetAttributes(&at, o[i].host) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!direct[i]) total += o[i].n * sizeof(double);
+  }
+  (void)hipGetLastError();   // (an unknown pointer is an error code of the query, not of this call)
   if (total > ctx->pinned_cap) {
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     ctx->pinned = nullptr; ctx->pinned_cap = 0;
@@ -57,10 +65,11 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
   if (herr_dev) RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(herr_host, herr_dev, sizeof(int), hipMemcpyDeviceToHost, s));
   size_t off = 0;
   for (int i = 0; i < count; ++i) {
-    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(p + off, o[i].dev, o[i].n * sizeof(double), hipMemcpyDeviceToHost, s));
-    off += o[i].n * sizeof(double);
+    RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(direct[i] ? (char *)o[i].host : p + off, o[i].dev, o[i].n * sizeof(double), hipMemcpyDeviceToHost, s));
+    if (!direct[i]) off += o[i].n * sizeof(double);
   }
   RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  if (total == 0) return RRTMG_OK;
   // pinned staging -> the caller's arrays, in slices on a few host threads (first touch of fresh pages dominates)
   unsigned nt = std::thread::hardware_concurrency();
   nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
@@ -69,6 +78,7 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
   auto work = [&](unsigned t) {
     size_t off2 = 0;
     for (int i = 0; i < count; ++i) {
+      if (direct[i]) continue;
       const size_t bytes = o[i].n * sizeof(double), per = (bytes / nt + 4095) & ~(size_t)4095;
       const size_t lo = (size_t)t * per, hi = lo + per < bytes ? lo + per : bytes;
       if (lo < bytes) memcpy((char *)o[i].host + lo, p + off2 + lo, hi - lo);

@@ -111,9 +111,11 @@ struct OutCopy { double *host; const double *dev; size_t n; };
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host);
 // Host arrays that only ADD something to the problem when they hold a non-zero -- band optical depths of clouds given directly
 // and of aerosols: 14 / 16 values per layer and column, 55-63 MB each at 8192 x 60, half of what a drop-in call would send over
-// PCIe, and all zeros unless the model has such clouds / aerosols -- are scanned on the host (memory rate) and not uploaded
-// when they are entirely +0.0: the device code then takes its "array absent" path, which adds the same +0.0.
+// PCIe, and all zeros unless the model has such clouds / aerosols -- are scanned on the host (memory rate, in the background
+// while the other inputs are uploaded) and not uploaded when they are entirely +0.0: the device code then takes its "array
+// absent" path, which adds the same +0.0.  (Only for arrays of tens of MB: a 4 MB array is uploaded sooner than scanned.)
 bool host_all_zero(const double *p, size_t n);
+constexpr size_t kZeroScanMin = (size_t)1 << 20;   // doubles (8 MB): below this an array is simply uploaded
 }  // namespace rrtmg
 
 #define RRTMG_HIP_CHECK(ctx, call)                                                                     \

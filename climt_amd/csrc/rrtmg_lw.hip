@@ -10,6 +10,8 @@
 //     lw_solve_all_kernel  one launch per variant (cloud-free / cloudy tiles): wavefront = tile(64 columns) x work item (4|2
 //                          g-points of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
 //     lw_fluxheat_kernel   <<<(tiles, levels/15), 16 waves>>>  band / g-point integration per interface + heating rates
+#include <future>
+
 #include "rrtmg_ctx.h"
 #include "rrtmg_lw_device.h"
 #include "rrtmg_lw_host.h"
@@ -206,33 +208,40 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
 
   bool ok = true;
-  auto in = [&](const double *p, size_t n, const char *name, bool required, bool zeros_are_absent = false) -> const double * {
+  auto in = [&](const double *p, size_t n, const char *name, bool required, std::future<bool> *all_zero = nullptr) -> const double * {
     if (!p) {
       if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
       return nullptr;
     }
     if (a->memspace == 1) return p;
-    if (zeros_are_absent && !required && n >= (size_t)1 << 16 && host_all_zero(p, n)) return nullptr;   // (rrtmg_ctx.h: nothing to add, nothing to send)
+    if (all_zero && all_zero->valid() && all_zero->get()) return nullptr;   // (rrtmg_ctx.h, host_all_zero: nothing to add, nothing to send)
     double *dp = (double *)ctx->buf(std::string("lw.in.") + name, n * sizeof(double));
     if (!dp) { ok = false; return nullptr; }
     if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
     return dp;
   };
+  // the band arrays that may turn out to be all zeros are scanned in the background while the other inputs go up
+  std::future<bool> z_tauaer, z_taucld;
+  if (a->memspace == 0 && nl * 16 >= kZeroScanMin) {
+    if (a->tauaer) z_tauaer = std::async(std::launch::async, host_all_zero, a->tauaer, nl * 16);
+    if (a->taucld && d.icld >= 1 && d.inflag != 0) z_taucld = std::async(std::launch::async, host_all_zero, a->taucld, nl * 16);
+  }
   d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
   d.tlev = in(a->tlev, nl1, "tlev", false); d.tsfc = in(a->tsfc, N, "tsfc", true);
   d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
   d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
-  d.cfc11 = in(a->cfc11vmr, nl, "cfc11", false, true); d.cfc12 = in(a->cfc12vmr, nl, "cfc12", false, true);
-  d.cfc22 = in(a->cfc22vmr, nl, "cfc22", false, true); d.ccl4 = in(a->ccl4vmr, nl, "ccl4", false, true);
+  d.cfc11 = in(a->cfc11vmr, nl, "cfc11", false); d.cfc12 = in(a->cfc12vmr, nl, "cfc12", false);
+  d.cfc22 = in(a->cfc22vmr, nl, "cfc22", false); d.ccl4 = in(a->ccl4vmr, nl, "ccl4", false);
   d.emis = in(a->emis, (size_t)N * 16, "emis", true);
-  d.tauaer = in(a->tauaer, nl * 16, "tauaer", false, true);
   const bool clouds = d.icld >= 1;
   if (clouds) {
     d.cldfr = in(a->cldfr, nl, "cldfr", true);
-    d.taucld = in(a->taucld, nl * 16, "taucld", d.inflag == 0, true);
+    d.taucld = in(a->taucld, nl * 16, "taucld", d.inflag == 0, &z_taucld);
     d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag >= 1); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag >= 1);
     d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
   }
+  d.tauaer = in(a->tauaer, nl * 16, "tauaer", false, &z_tauaer);
+  if (z_taucld.valid()) (void)z_taucld.get();
   if (!ok) return ctx->status;
 
   auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("lw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };

@@ -11,6 +11,8 @@
 //     sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel (cloudy tiles): wavefront = tile(64 columns) x work
 //                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS
 //     sw_fluxheat_kernel  <<<(tiles, levels/15), 16 waves>>>  g-point sum per interface + heating rates
+#include <future>
+
 #include "rrtmg_ctx.h"
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
@@ -299,18 +301,21 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
 
   // ---- inputs -----------------------------------------------------------------------------
   bool ok = true;
-  auto in = [&](const double *p, size_t n, const char *name, bool required, bool zeros_are_absent = false) -> const double * {
+  auto in = [&](const double *p, size_t n, const char *name, bool required, std::future<bool> *all_zero = nullptr) -> const double * {
     if (!p) {
       if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
       return nullptr;
     }
     if (a->memspace == 1) return p;
-    if (zeros_are_absent && !required && n >= (size_t)1 << 16 && host_all_zero(p, n)) return nullptr;   // (rrtmg_ctx.h: nothing to add, nothing to send)
+    if (all_zero && all_zero->valid() && all_zero->get()) return nullptr;   // (rrtmg_ctx.h, host_all_zero: nothing to add, nothing to send)
     double *dp = (double *)ctx->buf(std::string("sw.in.") + name, n * sizeof(double));
     if (!dp) { ok = false; return nullptr; }
     if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
     return dp;
   };
+  // the band array that may turn out to be all zeros is scanned in the background while the other inputs go up
+  std::future<bool> z_taucld;
+  if (a->memspace == 0 && nl * kSwNBand >= kZeroScanMin && a->taucld && d.icld >= 1 && d.inflag != 0) z_taucld = std::async(std::launch::async, host_all_zero, a->taucld, nl * kSwNBand);
   d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
   d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
   d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
@@ -321,7 +326,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds) {
     d.cldfr = in(a->cldfr, nl, "cldfr", true);
     const bool optics = (d.inflag == 0);
-    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics, true);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
+
     // single-scattering albedo / asymmetry / forward fraction are read only where the optics are given directly -- under
     // inflag 2 they would multiply an optical depth below cldmin = 1e-20 at most -- so host copies are not uploaded then
     const bool up = optics || a->memspace == 1;
@@ -330,6 +335,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     d.fsfcld = up ? in(a->fsfcld, nl * kSwNBand, "fsfcld", optics) : nullptr;
     d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag == 2); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag == 2);
     d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
+    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics, &z_taucld);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
   }
   const double *ecaer = nullptr;
   if (d.iaer == 10) {

@@ -57,7 +57,8 @@ class OutputPool:
     Only for outputs the library overwrites completely (the radiation components').
 
     Liveness is tracked explicitly, not through reference counts (whose values are an interpreter detail): the memory
-    belongs to a `bytearray`; each hand-out wraps it in a NEW root array (`np.frombuffer`), and what the caller receives
+    belongs to a `bytearray` (or a page-locked ctypes byte array); each hand-out wraps it in a NEW root array
+    (`np.frombuffer`), and what the caller receives
     -- and every slice, reshape or DataArray made from it -- is a view whose `.base` chain ends at that root (numpy
     collapses view chains to the first array whose own base is not an ndarray).  `weakref.finalize` on the root returns
     the bytearray to the free list when the last such view has died; an interpreter that collects later only delays the
@@ -79,7 +80,18 @@ class OutputPool:
         if lst:
             backing = lst.pop()
         else:
-            backing = bytearray(8 * int(np.prod(shape)))      # zero-filled, pages touched
+            backing = None
+            if self._out < 8 * self._keep:
+                # page-locked when the HIP runtime is there: the library's device-to-host copies land in it directly.  (A caller
+                # that keeps every result gets pageable arrays beyond the first few: page-locked memory is not for archives.)
+                try:
+                    from .._hip import pinned_buffer
+                    backing = pinned_buffer(8 * int(np.prod(shape)))
+                    np.frombuffer(backing, dtype=np.float64)[:] = 0.0
+                except Exception:
+                    backing = None
+            if backing is None:
+                backing = bytearray(8 * int(np.prod(shape)))      # zero-filled, pages touched
         root = np.frombuffer(backing, dtype=np.float64)
         weakref.finalize(root, self._release, key, backing)
         self._out += 1

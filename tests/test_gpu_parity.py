@@ -255,7 +255,7 @@ def test_all_zero_band_arrays_are_not_sent_and_count_as_zeros(gpu_ctx):
     from climt_amd import _hip
     from climt_amd._lib import LW_OUT, SW_OUT
     from climt_amd.synthetic import make_columns
-    N, L = 256, 40
+    N, L = 2048, 40   # (band arrays of >= 2**20 values are scanned: smaller ones are simply uploaded)
     c = make_columns(N, L, cloudy=True, seed=11); c.update(BASE); c.pop("lat", None)
     c["cldfr"] = (c["cldfr"] > 0.3).astype(float)   # (the shortwave without McICA takes overcast or clear layers only)
 
