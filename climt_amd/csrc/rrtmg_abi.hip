@@ -32,6 +32,12 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   RRTMG_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   if (!ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   if (!ctx->stream_lw) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_lw, hipStreamNonBlocking));
+  if (!ctx->hint) {
+    RRTMG_HIP_CHECK(ctx, hipHostMalloc((void **)&ctx->hint, 2 * sizeof(rrtmg_ctx::CallHint), hipHostMallocDefault));
+    for (int w = 0; w < 2; ++w) { ctx->hint[w].ntile = -1; ctx->hint[w].nlay = -1; ctx->hint[w].ncloudy = -1; }
+    RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->ncloudy_dev, 2 * sizeof(int)));
+    RRTMG_HIP_CHECK(ctx, hipMemset(ctx->ncloudy_dev, 0, 2 * sizeof(int)));
+  }
   if (!ctx->err_dev) {
     RRTMG_HIP_CHECK(ctx, hipMalloc((void **)&ctx->err_dev, 64));
     RRTMG_HIP_CHECK(ctx, hipMemset(ctx->err_dev, 0, 64));
@@ -146,7 +152,7 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   hipError_t e = hipGetDeviceCount(&n);
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
-  if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) c->chunk_tiles = v; }
+  if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) { c->chunk_tiles = v; c->chunk_auto = false; } }
   *out = c;
   if (e != hipSuccess || n <= 0)
     return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));
@@ -162,6 +168,8 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
   if (ctx->sw_tab_dev) (void)hipFree(ctx->sw_tab_dev);
   if (ctx->lw_tab_dev) (void)hipFree(ctx->lw_tab_dev);
   if (ctx->err_dev) (void)hipFree(ctx->err_dev);
+  if (ctx->ncloudy_dev) (void)hipFree(ctx->ncloudy_dev);
+  if (ctx->hint) (void)hipHostFree((void *)ctx->hint);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
   for (int w = 0; w < 4; ++w)
     for (hipEvent_t e : ctx->ev[w])

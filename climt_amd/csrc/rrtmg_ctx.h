@@ -34,6 +34,16 @@ struct rrtmg_ctx {
   // 128 tiles = 8192 columns: one full round of the clear-sky shortwave kernel (256 workgroups of 16 tiles x 32 items);
   // measured 1-3 % faster than 512 on grids of 16 384 ... 131 072 columns (64: the launches no longer fill the GPU)
   int chunk_tiles = 128;
+  bool chunk_auto = true;            // false: RRTMG_HIP_CHUNK_TILES was given
+  // What the PREVIOUS call of a spectrum [sw|lw] found -- tiles, layers, tiles with a cloud -- for sizing and ordering the
+  // launches of the next one.  The count is left in page-locked memory by the call's last kernel (which also clears the counter) and read
+  // WITHOUT waiting when the next call is enqueued (stale, or missing, in a loop that runs ahead of the GPU): a hint.  Every
+  // value gives the same results; what it moves is which of the two solve variants is enqueued first (the one expected to
+  // find no tile of its kind: its workgroups are then placed while the stream has the GPU, not after the other spectrum has
+  // taken the CUs) and the chunk depth of a cloudy grid with more than 80 layers.
+  struct CallHint { int ntile, nlay, ncloudy; };
+  volatile CallHint *hint = nullptr;   // [2], page-locked
+  int *ncloudy_dev = nullptr;          // [2]
   // KISS jump-ahead operators [sw|lw]: host copy, the key they were built for, the device buffer they were uploaded to
   std::vector<uint32_t> kiss_host[2][2];   // two staging copies per spectrum: a rebuild never waits for the previous upload
   hipEvent_t kiss_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // recorded after the upload from kiss_host[w][k]

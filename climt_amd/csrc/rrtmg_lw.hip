@@ -54,6 +54,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) lw_prep_fused_kernel(LwDev d,
       int any = 0;
       for (int k = 0; k < kPrepWaves; ++k) any |= sh_any[k];
       d.tile_cld[tile] = any; sh_cld = any;
+      if (any) atomicAdd(d.ncloudy, 1);
     }
   }
   if (!clouds) return;
@@ -134,6 +135,8 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
 // band integration AND heating rates in one launch (see sw_fluxheat_kernel)
 constexpr int kFluxLev = 15;   // 16 waves per workgroup: the halo level is 1 in 16 of the partial-plane reads
 __global__ void __launch_bounds__(64 * (kFluxLev + 1)) lw_fluxheat_kernel(LwDev d, LwTab T, int tile0) {
+  // (the call's last launch leaves the preparation kernels' cloudy-tile count where the host will look for it, and clears it)
+  if (d.hint_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *d.hint_out = *d.ncloudy; *d.ncloudy = 0; }
   const int tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
   const int col = tile * 64 + lane, lev = blockIdx.y * kFluxLev + j;
   __shared__ double net[kFluxLev + 1][64], netc[kFluxLev + 1][64];
@@ -250,6 +253,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   d.laytrop = (int32_t *)ctx->buf("lw.w.laytrop", (size_t)N * 4);
   d.ncbands = (int32_t *)ctx->buf("lw.w.ncbands", (size_t)N * 4);
   d.tile_cld = (int32_t *)ctx->buf("lw.w.tilecld", (size_t)((N + 63) / 64) * 4);
+  d.ncloudy = ctx->ncloudy_dev + 1;
   if (maxrand) d.mr = wd("mr", lw_mr_size(N, L));
   if (!d.laytrop || !d.ncbands || !d.tile_cld) ok = false;
   if (clouds) d.ctau = wd("ctau", nl * 16);
@@ -261,7 +265,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   }
   const int ntile = (N + 63) / 64;
   const int nk = d.idrv ? 6 : 4;
-  const int ctile = ntile < ctx->chunk_tiles ? ntile : ctx->chunk_tiles;   // tiles per solve chunk
+  // what the previous call found (rrtmg_ctx::CallHint): read without waiting, used for speed only
+  const int hint_cloudy = (ctx->hint[1].ntile == ntile && ctx->hint[1].nlay == L) ? ctx->hint[1].ncloudy : -1;
+  int chunk_tiles = ctx->chunk_tiles;
+  if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
+  const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
   d.scratch = wd("scratch", (size_t)ctile * kLwNGpt * LF_N * L * 64);
   d.part = wd("part", (size_t)T.nitem * nk * (L + 1) * ctile * 64);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
@@ -333,17 +341,24 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const int ci = t0 / ctile;
-    (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
-    hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
-    (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
-    if (clouds) {
+    auto clear_variant = [&]() {
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
+      hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
+    };
+    auto cloudy_variant = [&]() {
       (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
       if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
       (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
-    }
+    };
+    // the variant expected to find nothing goes first (see sw_fluxes_impl)
+    if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
+    else { clear_variant(); if (clouds) cloudy_variant(); }
+    d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[1].ncloudy : nullptr;
     hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
+  ctx->hint[1].ntile = ntile; ctx->hint[1].nlay = L;
   ctx->ev_chunks[1] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[3] = clouds ? ctx->ev_chunks[1] : 0;
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 #ifdef RRTMG_PROFILE

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * kPrepWaves) sw_prep_fused_kernel(SwDev d,
     for (int b = w; b < kSwNBand; b += kPrepWaves) sw_prep_column(d, T, col, b, b + 1, sh_idx + lane, 64);
   if (w == 0) {
     const unsigned long long any = __ballot(act && d.anycld[col] != 0);
-    if (lane == 0) { d.tile_cld[tile] = any != 0ull; sh_cld = any != 0ull; }
+    if (lane == 0) { d.tile_cld[tile] = any != 0ull; sh_cld = any != 0ull; if (any) atomicAdd(d.ncloudy, 1); }
   }
   if (!clouds) return;
   __syncthreads();
@@ -180,6 +180,8 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
 // -- the same differences of the same doubles as sw_heat_layer reads back from memory.
 constexpr int kFluxLev = 15;   // 16 waves per workgroup: the halo level is 1 in 16 of the partial-plane reads
 __global__ void __launch_bounds__(64 * (kFluxLev + 1)) sw_fluxheat_kernel(SwDev d, SwTab T, int tile0) {
+  // (the call's last launch leaves the preparation kernels' cloudy-tile count where the host will look for it, and clears it)
+  if (d.hint_out && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) { *d.hint_out = *d.ncloudy; *d.ncloudy = 0; }
   const int tile = tile0 + blockIdx.x, lane = threadIdx.x & 63, j = threadIdx.x >> 6;
   const int col = tile * 64 + lane, lev = blockIdx.y * kFluxLev + j;
   __shared__ double net[kFluxLev + 1][64], netc[kFluxLev + 1][64];
@@ -353,12 +355,17 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   d.laytrop = (int32_t *)ctx->buf("sw.w.laytrop", (size_t)N * 4);
   d.laysolfr = (int32_t *)ctx->buf("sw.w.laysolfr", (size_t)N * 4 * kSwNBand); d.anycld = (int32_t *)ctx->buf("sw.w.anycld", (size_t)N * 4);
   d.tile_cld = (int32_t *)ctx->buf("sw.w.tilecld", (size_t)((N + 63) / 64) * 4);
+  d.ncloudy = ctx->ncloudy_dev;
   if (!d.laytrop || !d.laysolfr || !d.anycld || !d.tile_cld) ok = false;
   if (clouds) { d.ctau = wd("ctau", nl * kSwNBand); d.cssa = wd("cssa", nl * kSwNBand); d.casm = wd("casm", nl * kSwNBand); }
   d.nw = (L + 63) / 64;
   if (clouds && d.mcica) { d.mask = (uint64_t *)ctx->buf("sw.w.mask", (size_t)kSwNGpt * d.nw * N * 8); if (!d.mask) ok = false; }
   const int ntile = (N + 63) / 64;
-  const int ctile = ntile < ctx->chunk_tiles ? ntile : ctx->chunk_tiles;   // tiles per solve chunk
+  // what the previous call found (rrtmg_ctx::CallHint): read without waiting, used for speed only
+  const int hint_cloudy = (ctx->hint[0].ntile == ntile && ctx->hint[0].nlay == L) ? ctx->hint[0].ncloudy : -1;
+  int chunk_tiles = ctx->chunk_tiles;
+  if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
+  const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
   d.scratch = wd("scratch", (size_t)ctile * kSwNGpt * F_NTOT * L * 64);
   d.part = wd("part", (size_t)kSwNSlot * 4 * (L + 1) * ctile * 64);
   if (!svar_col.empty()) {   // per-column solar-variability multipliers (rare: facular/sunspot amplitudes != 1)
@@ -423,16 +430,23 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
     const int ci = t0 / ctile;
-    (void)hipEventRecord(ctx->chunk_event(0, ci, 0), s);
-    hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem), wg, 0, s, d, T, t0, nt);
-    (void)hipEventRecord(ctx->chunk_event(0, ci, 1), s);
-    if (clouds) {
+    auto clear_variant = [&]() {
+      (void)hipEventRecord(ctx->chunk_event(0, ci, 0), s);
+      hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem), wg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(0, ci, 1), s);
+    };
+    auto cloudy_variant = [&]() {
       (void)hipEventRecord(ctx->chunk_event(2, ci, 0), s);
       hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem), dim3(64 * kC4Waves), 0, s, d, T, t0, nt);
       (void)hipEventRecord(ctx->chunk_event(2, ci, 1), s);
-    }
+    };
+    // the variant expected to find nothing goes first (order is speed only: each tile belongs to exactly one of them)
+    if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
+    else { clear_variant(); if (clouds) cloudy_variant(); }
+    d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[0].ncloudy : nullptr;
     hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
+  ctx->hint[0].ntile = ntile; ctx->hint[0].nlay = L;
   ctx->ev_chunks[0] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[2] = clouds ? ctx->ev_chunks[0] : 0;
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
 

@@ -88,6 +88,8 @@ struct SwDev {
   int32_t *laysolfr;   // [14][col], 1-based layer, 0 = source never set
   int32_t *anycld;     // [col] 1 if any layer has cldfr > 0
   int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has a cloud (selects the solve kernel variant)
+  int32_t *ncloudy;    // number of tiles with tile_cld set, counted by the preparation kernels (rrtmg_ctx::CallHint) ...
+  int32_t *hint_out;   // ... and where the call's LAST integration launch leaves it for the host (page-locked; nullptr in the others)
   double *cossza;      // [col]
   double *pdp;         // [lay][col]
   double *ctau, *cssa, *casm;   // delta-scaled cloud optics [14][lay][col]
