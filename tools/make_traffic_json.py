@@ -12,7 +12,9 @@ Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py loo
 launch of one column chunk.
   "step|<columns>|<levels>|<clear|cloudy>" = the same counters summed over EVERY kernel of one LW+SW step (preparation,
              cloud optics / sub-column masks, both solve variants, flux + heating): sum over kernels of (average per dispatch x
-             dispatches) / steps, steps = dispatches of sw_prep_fused_kernel (one per step); "step_kernels|..." lists the terms.
+             dispatches) / steps, steps = dispatches of sw_prep_fused_kernel / column chunks of a call (the preparation is
+             launched once per chunk of 128 tiles = 8192 columns, the default RRTMG_HIP_CHUNK_TILES); "step_kernels|..." lists
+             the terms.
 usage: tools/make_traffic_json.py [round=r03]"""
 import json
 import os
@@ -50,7 +52,8 @@ for mode in ("clear", "cloudy"):
             if b > 1.0e6:
                 traffic["%s|%d|60|%s" % (k, ncol, mode)] = b
         fa, wa = get_all("%s_pmc_%s_FETCH_SIZE%s.txt" % (rnd, mode, tag), "FETCH_SIZE"), get_all("%s_pmc_%s_WRITE_SIZE%s.txt" % (rnd, mode, tag), "WRITE_SIZE")
-        steps = fa.get("rrtmg::sw_prep_fused_kernel", (0, 0))[1]
+        chunks = max(1, -(-ncol // (128 * 64)))
+        steps = fa.get("rrtmg::sw_prep_fused_kernel", (0, 0))[1] // chunks
         if steps and len(fa) > 4:      # (a pass that recorded every kernel, not only the solve kernels)
             terms = {k: (2.0 * fa[k][0] * fa[k][1] + wa.get(k, (0.0, 0))[0] * wa.get(k, (0.0, 0))[1]) * 1024.0 / steps for k in fa}
             traffic["step|%d|60|%s" % (ncol, mode)] = sum(terms.values())
