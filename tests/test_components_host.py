@@ -167,6 +167,36 @@ def test_unit_conversion_of_the_sympl_standin():
         sc.convert_units(1.0, "Pa", "K")
 
 
+def test_staged_input_products_and_extraction_plans():
+    """The components form their input products (unit conversions, water-vapour mixing ratio) in the background into kept
+    buffers (InputStaging) and work the route of every input out once per state STRUCTURE: the values are those of the plain
+    expressions, and a state whose units or axis order change gets its own plan."""
+    from climt_amd.rrtmg.common import InputStaging
+    from climt_amd._util import mass_to_volume_mixing_ratio
+    rng = np.random.default_rng(3)
+    q = rng.uniform(0, 0.02, (60, 500))
+    st = InputStaging()
+    a = st.scaled("q", q, 28.964, 18.02, pieces=4); b = st.scaled("p", q, 0.01)
+    st.wait()
+    assert np.array_equal(a, mass_to_volume_mixing_ratio(q, 18.02)) and np.array_equal(b, q * 0.01)
+    assert st.scaled("q", q, 28.964, 18.02) is a     # the buffer is kept
+    st.wait()
+    if sc.HAVE_SYMPL:
+        return
+    state, _, _ = load_cache_case("TestRRTMGShortwave", "column")
+    comp = climt_amd.RRTMGShortwave()
+    t0, d0 = comp(state)
+    other = dict(state)
+    p = state["air_pressure"]
+    other["air_pressure"] = sc.DataArray(p.values / 100.0, dims=p.dims, attrs={"units": "hPa"})
+    t1, d1 = comp(other)
+    assert len(comp._plans) == 2
+    for k in d0:
+        assert np.allclose(d0[k].values, d1[k].values, rtol=1e-12, atol=1e-12), k
+    t2, d2 = comp(state)          # back to the first structure: its plan is still there
+    assert len(comp._plans) == 2 and all(np.array_equal(d0[k].values, d2[k].values) for k in d0)
+
+
 def test_instellation_time_arithmetic_matches_oracle():
     """days since 2000-01-01 12:00 (the only host arithmetic of the Instellation drop-in), incl. sub-second times."""
     import datetime
