@@ -51,6 +51,9 @@ struct rrtmg_ctx {
   hipEvent_t sync_ev[2] = {nullptr, nullptr};   // rrtmg_hip_stream_wait: "everything enqueued so far" on stream / stream_lw
   int kiss_key[2][4] = {{-1, -1, -1, -1}, {-1, -1, -1, -1}};
   const void *kiss_dev[2] = {nullptr, nullptr};
+  // Mersenne-twister jump polynomials [sw|lw] on the device: the (first draw, stride, runs, piece, pieces) they were built for
+  uint64_t mt_key[2][5] = {{~0ull, ~0ull, ~0ull, ~0ull, ~0ull}, {~0ull, ~0ull, ~0ull, ~0ull, ~0ull}};
+  const void *mt_dev[2] = {nullptr, nullptr};
   std::string err;
   int status = 0;
   rrtmg::Constants k{};
@@ -147,7 +150,11 @@ int sw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob);
 int lw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob);
 int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
                     const double *play, const double *cldfrac, double *cldfmcl);
-// Mersenne-twister CDF stream of the reference (mcica_random_numbers.f90:77-302) -> bit mask on host
+// Mersenne-twister sub-column masks on the device (rrtmg_mt_device.hip): cldfr, mask device pointers, everything on stream s
+int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, uint64_t *mask, int nw,
+                   int col0, int ncol_total, hipStream_t s);
+// Mersenne-twister CDF stream of the reference (mcica_random_numbers.f90:77-302) -> bit mask on the HOST: the sequential
+// restatement the device path is tested against (tests/emu); not called by the library
 void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw,
                   int col0 = 0, int ncol_total = 0);
 }  // namespace rrtmg

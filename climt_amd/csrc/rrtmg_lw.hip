@@ -320,13 +320,8 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
         if (!jumps) return ctx->status;
         hipLaunchKernelGGL(kiss_mask_kernel, dim3(kLwNGpt, ntile), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
       } else {
-        std::vector<double> cf(nl);
-        if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
-        else cf.assign(a->cldfr, a->cldfr + nl);
-        std::vector<uint64_t> hm;
-        mt_mask_host(N, L, kLwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw, a->shard_col0, a->shard_ncol);
-        RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
-        RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        rc = mt_mask_device(ctx, 1, N, L, kLwNGpt, d.icld, a->permuteseed, d.cldfr, d.mask, d.nw, a->shard_col0, a->shard_ncol, s);
+        if (rc) return rc;
       }
       hipLaunchKernelGGL(lw_anymask_kernel, gcol, blk, 0, s, d);
     }

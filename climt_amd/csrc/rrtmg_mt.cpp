@@ -1,5 +1,7 @@
-// rrtmg_mt.cpp -- host-side Mersenne-twister sub-column mask (the reference's MT stream is one global
-// sequential stream over (sub-column, column, layer), so it is generated on the host and uploaded).
+// rrtmg_mt.cpp -- the reference's Mersenne-twister sub-column mask as ONE sequential stream on the host, the way the
+// reference generates it.  The library builds the same bits on the device by jump-ahead (rrtmg_mt_device.hip,
+// rrtmg_mt_jump.cpp) and does not call this; the host emulation of the tests does (tests/emu), and the device path is
+// tested bit for bit against it.
 #include <cstdint>
 #include <vector>
 

@@ -209,7 +209,7 @@ void free_sw_desc(rrtmg_ctx *ctx) {
   ctx->sw_desc = nullptr;
 }
 
-// stand-alone sub-column generator (host pointers): mask on the device (kissvec) or host (MT)
+// stand-alone sub-column generator (host pointers): the mask is built on the device by either generator
 int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
                     const double *play, const double *cldfrac, double *cldfmcl) {
   if (ncol <= 0 || nlay <= 0 || !play || !cldfrac || !cldfmcl) return ctx->fail(RRTMG_ERR_ARG, "mcica_mask: bad argument");
@@ -218,15 +218,6 @@ int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int
   const int nw = (nlay + 63) / 64;
   const size_t nl = (size_t)ncol * nlay;
   if (icld == 0) return RRTMG_OK;   // mcica_subcol_*: "if (icld.eq.0) return" -- outputs untouched
-  if (irng != 0) {
-    std::vector<uint64_t> hm;
-    mt_mask_host(ncol, nlay, nsub, icld, permuteseed, cldfrac, hm, nw);
-    for (int l = 0; l < nlay; ++l)
-      for (int c = 0; c < ncol; ++c)
-        for (int g = 0; g < nsub; ++g)
-          cldfmcl[((size_t)l * ncol + c) * nsub + g] = ((hm[((size_t)g * nw + (l >> 6)) * ncol + c] >> (l & 63)) & 1ull) ? 1.0 : 0.0;
-    return RRTMG_OK;
-  }
   int rc = ctx_prepare_device(ctx);
   if (rc) return rc;
   hipStream_t s = ctx->stream;
@@ -238,9 +229,14 @@ int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(dc, cldfrac, nl * 8, hipMemcpyHostToDevice, s));
   RRTMG_HIP_CHECK(ctx, hipMemsetAsync(ctx->err_dev, 0, sizeof(int), s));
   const int ntile = (ncol + 63) / 64;
-  const uint32_t *jumps = kiss_jumps_device(ctx, which == 0 ? 0 : 1, nsub, nlay, icld, permuteseed, s);
-  if (!jumps) return ctx->status;
-  hipLaunchKernelGGL(kiss_mask_kernel, dim3(nsub, ntile), dim3(64), 0, s, ncol, nlay, icld, dp, dc, mk, nw, ctx->err_dev, jumps);
+  if (irng != 0) {
+    rc = mt_mask_device(ctx, which == 0 ? 0 : 1, ncol, nlay, nsub, icld, permuteseed, dc, mk, nw, 0, 0, s);
+    if (rc) return rc;
+  } else {
+    const uint32_t *jumps = kiss_jumps_device(ctx, which == 0 ? 0 : 1, nsub, nlay, icld, permuteseed, s);
+    if (!jumps) return ctx->status;
+    hipLaunchKernelGGL(kiss_mask_kernel, dim3(nsub, ntile), dim3(64), 0, s, ncol, nlay, icld, dp, dc, mk, nw, ctx->err_dev, jumps);
+  }
   hipLaunchKernelGGL(cldfmcl_from_mask_kernel, dim3(ntile, nsub), dim3(64), 0, s, ncol, nlay, nsub, mk, nw, dm);
   int herr = 0;
   RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(&herr, ctx->err_dev, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -409,13 +405,8 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
         if (!jumps) return ctx->status;
         hipLaunchKernelGGL(kiss_mask_kernel, dim3(kSwNGpt, ntile), blk, 0, s, N, L, d.icld, d.play, d.cldfr, d.mask, d.nw, d.err, jumps);
       } else {
-        std::vector<double> cf(nl);
-        if (a->memspace == 1) { RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(cf.data(), a->cldfr, nl * 8, hipMemcpyDeviceToHost, s)); RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s)); }
-        else cf.assign(a->cldfr, a->cldfr + nl);
-        std::vector<uint64_t> hm;
-        mt_mask_host(N, L, kSwNGpt, d.icld, a->permuteseed, cf.data(), hm, d.nw, a->shard_col0, a->shard_ncol);
-        RRTMG_HIP_CHECK(ctx, hipMemcpyAsync(d.mask, hm.data(), hm.size() * 8, hipMemcpyHostToDevice, s));
-        RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+        rc = mt_mask_device(ctx, 0, N, L, kSwNGpt, d.icld, a->permuteseed, d.cldfr, d.mask, d.nw, a->shard_col0, a->shard_ncol, s);
+        if (rc) return rc;
       }
     }
   }

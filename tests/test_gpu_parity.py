@@ -443,6 +443,31 @@ def test_mcica_mask_matches_reference_generator(gpu_ctx):
             assert np.array_equal(a, b), (which, icld, irng)
 
 
+def test_mersenne_twister_masks_by_jump_ahead_equal_the_sequential_stream(gpu_ctx):
+    """The reference's default generator is ONE sequential MT19937 stream over (sub-column, column, layer).  The device builds
+    it by polynomial jump-ahead, one segment per sub-column (rrtmg_mt_device.hip): every mask bit must equal the sequential
+    host stream's (tests/emu, checked against the reference Fortran masks) -- on a ragged grid of more than 64 layers, for the
+    three overlaps, for several seeds, and for shards of a larger grid (their segments start in the middle of the stream)."""
+    from climt_amd.distributed import slice_columns
+    from climt_amd.synthetic import make_columns
+    from helpers import EmuContext
+    emu = EmuContext()
+    c = make_columns(300, 70, cloudy=True, seed=19)
+    for which in ("sw", "lw"):
+        for icld, seed in ((1, 1), (2, 209652396), (3, 77), (2, 2 ** 31 - 2)):
+            a = gpu_ctx.mcica_mask(which, c["play"], c["cldfr"], icld, seed, 1)
+            b = emu.mcica_mask(which, c["play"], c["cldfr"], icld, seed, 1)
+            assert np.array_equal(a, b), (which, icld, seed)
+    # shards: columns lo..hi of a 1000-column grid, through the flux calls (shard_col0 / shard_ncol), against the whole grid
+    big = make_columns(1000, 40, cloudy=True, seed=23); big.pop("lat"); big.update(BASE); big.update(irng=1, permuteseed=4711, icld=2)
+    sw, lw = gpu_ctx.sw_fluxes(big, mcica=True), gpu_ctx.lw_fluxes(big, mcica=True)
+    for lo, hi in ((0, 128), (320, 704), (960, 1000)):
+        sub = slice_columns(big, lo, hi); sub.update(shard_col0=lo, shard_ncol=1000)
+        s, l = gpu_ctx.sw_fluxes(sub, mcica=True), gpu_ctx.lw_fluxes(sub, mcica=True)
+        assert all(np.array_equal(sw[k][:, lo:hi], s[k]) for k in sw), (lo, hi)
+        assert all(np.array_equal(lw[k][:, lo:hi], l[k]) for k in lw), (lo, hi)
+
+
 def test_reference_compatible_entry_points(gpu_ctx):
     """The symbols climt's Cython shims bind, called exactly as _rrtmg_sw.pyx does (pointers to scalars)."""
     from helpers import CONSTANTS, CPDAIR
