@@ -627,6 +627,25 @@ def main():
                                                               "sympl-style DataArrays in, tendencies + diagnostics out" % (N // 128, L)}
                 except Exception as e:   # pragma: no cover
                     extra["end_to_end_components"] = {"error": repr(e)[:200]}
+                # (c') the same classes with McICA and the reference's DEFAULT generator (Mersenne twister), clouds in ten layers
+                if not cloudy:
+                    try:
+                        sw_m = climt_amd.RRTMGShortwave(mcica=True, cloud_overlap_method="maximum_random")
+                        lw_m = climt_amd.RRTMGLongwave(mcica=True, cloud_overlap_method="maximum_random", allow_synthetic_tables=True)
+                        st_m = climt_amd.get_default_state([sw_m, lw_m], grid_state=climt_amd.get_grid(nx=128, ny=N // 128, nz=L))
+                        st_m["cloud_area_fraction_in_atmosphere_layer"].values[L // 3:L // 2] = 0.4
+                        st_m["mass_content_of_cloud_liquid_water_in_atmosphere_layer"].values[L // 3:L // 2] = 0.03
+                        sw_m(st_m); lw_m(st_m)      # (the first call of a grid shape builds the generator's jump polynomials: ~0.5 s, once)
+                        t0 = time.perf_counter()
+                        for _ in range(n_c):
+                            sw_m(st_m); lw_m(st_m)
+                        clm = (time.perf_counter() - t0) / n_c
+                        extra["end_to_end_components_mcica"] = {"value": 128 * (N // 128) / clm, "unit": "columns/s", "ms_per_step": clm * 1e3, "calls": n_c,
+                                                                "note": "RRTMGShortwave(mcica=True) + RRTMGLongwave(mcica=True), maximum-random overlap, the reference's default "
+                                                                        "random_number_generator (mersenne_twister: its one sequential stream is built on the device by jump-ahead), "
+                                                                        "cloud fraction 0.4 in %d layers of get_default_state(128 x %d x %d)" % (L // 2 - L // 3, N // 128, L)}
+                    except Exception as e:   # pragma: no cover
+                        extra["end_to_end_components_mcica"] = {"error": repr(e)[:200]}
                 # (d) SURVEY 8(f)3: the whole model step either side of the path with the state resident on the device --
                 # Instellation -> RRTMG SW + LW (every step) -> Adams-Bashforth -> SlabSurface on a DeviceState, through the
                 # same component classes; the host does not wait between steps
