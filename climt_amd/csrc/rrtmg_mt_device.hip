@@ -221,10 +221,13 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
   }
   static const bool big_lds = hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMtJumpLds) == hipSuccess;
   if (!big_lds) return ctx->fail(RRTMG_ERR_HIP, "mt_jump_kernel: %d bytes of dynamic LDS refused", kMtJumpLds);
+  const size_t mask_lds = (size_t)64 * ((icld == 3 ? 1 : nlay) | 1) * 4;   // (256 layers: 64.25 KB, just over what a kernel may have unasked)
+  static const bool mask_lds_ok = hipFuncSetAttribute((const void *)mt_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4) == hipSuccess;
+  if (mask_lds > 64 * 1024 && !mask_lds_ok) return ctx->fail(RRTMG_ERR_HIP, "mt_mask_kernel: %zu bytes of dynamic LDS refused", mask_lds);
   hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(64), 0, s, (uint32_t)seed, x);
   hipLaunchKernelGGL(mt_jump_kernel, dim3(nseg), dim3(kMtJumpThreads), (size_t)kMtJumpLds, s, x, lists, counts, win);
   hipLaunchKernelGGL(mt_stream_kernel, dim3(nseg), dim3(64), 0, s, win, count, piece, npiece, draws);
-  hipLaunchKernelGGL(mt_mask_kernel, dim3(nsub, (ncol + 63) / 64), dim3(64), (size_t)64 * ((icld == 3 ? 1 : nlay) | 1) * 4, s, ncol, nlay, icld, cldfr, draws, mask, nw);
+  hipLaunchKernelGGL(mt_mask_kernel, dim3(nsub, (ncol + 63) / 64), dim3(64), mask_lds, s, ncol, nlay, icld, cldfr, draws, mask, nw);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
   return RRTMG_OK;
 }

@@ -458,6 +458,9 @@ def test_mersenne_twister_masks_by_jump_ahead_equal_the_sequential_stream(gpu_ct
             a = gpu_ctx.mcica_mask(which, c["play"], c["cldfr"], icld, seed, 1)
             b = emu.mcica_mask(which, c["play"], c["cldfr"], icld, seed, 1)
             assert np.array_equal(a, b), (which, icld, seed)
+    deep = make_columns(70, 256, cloudy=True, seed=5)      # the deepest grid the library takes: four mask words, 64.25 KB of LDS
+    for which in ("sw", "lw"):
+        assert np.array_equal(gpu_ctx.mcica_mask(which, deep["play"], deep["cldfr"], 2, 31, 1), emu.mcica_mask(which, deep["play"], deep["cldfr"], 2, 31, 1))
     # shards: columns lo..hi of a 1000-column grid, through the flux calls (shard_col0 / shard_ncol), against the whole grid
     big = make_columns(1000, 40, cloudy=True, seed=23); big.pop("lat"); big.update(BASE); big.update(irng=1, permuteseed=4711, icld=2)
     sw, lw = gpu_ctx.sw_fluxes(big, mcica=True), gpu_ctx.lw_fluxes(big, mcica=True)
