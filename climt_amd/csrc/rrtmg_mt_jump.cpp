@@ -84,18 +84,58 @@ const Poly &phi() {
   return p;
 }
 
-// r = a * b mod phi (all of degree < 19937), Horner over the bits of a
-void mulmod(const uint64_t *a, const uint64_t *b, uint64_t *r) {
-  const uint64_t *f = phi().data();
-  uint64_t acc[kW];
-  std::memset(acc, 0, sizeof acc);
-  for (int i = kDeg - 1; i >= 0; --i) {
-    uint64_t carry = 0;
-    for (int w = 0; w < kW; ++w) { const uint64_t v = acc[w]; acc[w] = (v << 1) | carry; carry = v >> 63; }
-    if (bit(acc, kDeg)) for (int w = 0; w < kW; ++w) acc[w] ^= f[w];
-    if (bit(a, i)) for (int w = 0; w < kW; ++w) acc[w] ^= b[w];
+// acc = acc * t^8 mod phi, acc of degree < 19937: shift by one byte, fold the byte that left the top back in (red[o] = o(t) *
+// t^19937 mod phi, o = 0..255)
+struct Phi8 {
+  uint64_t red[256][kW];
+  Phi8() {
+    const uint64_t *f = phi().data();
+    std::memset(red, 0, sizeof red);
+    // t^19937 = phi - t^19937 (the lower terms of phi); then red[2o] = red[o] * t, red[2o + 1] = red[2o] ^ red[1]
+    for (int w = 0; w < kW; ++w) red[1][w] = f[w];
+    red[1][kDeg >> 6] &= ~(1ull << (kDeg & 63));
+    for (int o = 2; o < 256; ++o) {
+      const uint64_t *h = red[o >> 1];
+      uint64_t carry = 0;
+      for (int w = 0; w < kW; ++w) { const uint64_t v = h[w]; red[o][w] = (v << 1) | carry; carry = v >> 63; }
+      if (bit(red[o], kDeg)) { red[o][kDeg >> 6] &= ~(1ull << (kDeg & 63)); for (int w = 0; w < kW; ++w) red[o][w] ^= red[1][w]; }
+      if (o & 1) for (int w = 0; w < kW; ++w) red[o][w] ^= red[1][w];
+    }
   }
-  std::memcpy(r, acc, sizeof acc);
+};
+const Phi8 &phi8() {
+  static const Phi8 *p = new Phi8();
+  return *p;
+}
+
+// r = a * b mod phi (all of degree < 19937): Horner over the BYTES of a, with the 256 multiples v(t) * b of b in a table
+// (0.9 ms instead of the 5.5 ms of a bit-by-bit Horner)
+void mulmod(const uint64_t *a, const uint64_t *b, uint64_t *r) {
+  const Phi8 &R = phi8();
+  std::vector<uint64_t> tab((size_t)256 * kW, 0);
+  auto T = [&](int v) { return &tab[(size_t)v * kW]; };
+  std::memcpy(T(1), b, kW * sizeof(uint64_t));
+  for (int v = 2; v < 256; ++v) {
+    const uint64_t *h = T(v >> 1);
+    uint64_t *d = T(v), carry = 0;
+    for (int w = 0; w < kW; ++w) { const uint64_t x = h[w]; d[w] = (x << 1) | carry; carry = x >> 63; }
+    if (bit(d, kDeg)) { d[kDeg >> 6] &= ~(1ull << (kDeg & 63)); for (int w = 0; w < kW; ++w) d[w] ^= R.red[1][w]; }
+    if (v & 1) for (int w = 0; w < kW; ++w) d[w] ^= b[w];
+  }
+  uint64_t acc[kW + 1];
+  std::memset(acc, 0, sizeof acc);
+  const int nbytes = (kDeg + 7) / 8;   // 2493: bits 0 .. 19943 of a (the top ones are zero)
+  for (int i = nbytes - 1; i >= 0; --i) {
+    // acc *= t^8: the byte that crosses bit 19937 comes back through red[]
+    const unsigned over = (unsigned)((acc[kDeg >> 6] >> ((kDeg & 63) - 8)) & 0xffu);   // bits 19929 .. 19936
+    uint64_t carry = 0;
+    for (int w = 0; w < kW; ++w) { const uint64_t v = acc[w]; acc[w] = (v << 8) | carry; carry = v >> 56; }
+    acc[kDeg >> 6] &= (1ull << (kDeg & 63)) - 1;
+    const unsigned av = (unsigned)((a[i >> 3] >> (8 * (i & 7))) & 0xffu);
+    const uint64_t *ro = R.red[over], *tv = T((int)av);
+    for (int w = 0; w < kW; ++w) acc[w] ^= ro[w] ^ tv[w];
+  }
+  std::memcpy(r, acc, kW * sizeof(uint64_t));
 }
 
 // r = t^e mod phi
@@ -129,7 +169,7 @@ constexpr int kMtListPad = 19937 + 624;   // (its words are beyond what the devi
 // (a segment that starts at draw 0 needs no jump -- its window is the seed's own: count -1).  lists[(g * npiece + s) *
 // kMtListMax ..] holds the exponents i of the polynomial's terms, padded to a multiple of 16 with kMtListPad, whose words read
 // as zeros on the device; counts[] the padded lengths.  Built on a few threads: t^stride and the t^(s * piece) once, then
-// one multiplication per segment (5 ms each; 140 sub-columns x 4 pieces: 0.5 s once per grid shape); cached, and COPIED out.
+// one multiplication per segment (2.5 ms each; 140 sub-columns x 4 pieces: 0.2 s once per grid shape); cached, and COPIED out.
 // Returns false if phi could not be established (never observed; the caller reports it).
 bool mt_jump_lists(uint64_t first, uint64_t stride, int nsub, uint64_t piece, int npiece, std::vector<uint32_t> &lists, std::vector<int32_t> &counts) {
   static std::mutex mu;
