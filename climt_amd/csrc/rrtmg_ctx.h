@@ -153,8 +153,4 @@ int mcica_mask_impl(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int
 // Mersenne-twister sub-column masks on the device (rrtmg_mt_device.hip): cldfr, mask device pointers, everything on stream s
 int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, uint64_t *mask, int nw,
                    int col0, int ncol_total, hipStream_t s);
-// Mersenne-twister CDF stream of the reference (mcica_random_numbers.f90:77-302) -> bit mask on the HOST: the sequential
-// restatement the device path is tested against (tests/emu); not called by the library
-void mt_mask_host(int ncol, int nlay, int nsub, int icld, int seed, const double *cldfr, std::vector<uint64_t> &mask, int nw,
-                  int col0 = 0, int ncol_total = 0);
 }  // namespace rrtmg

@@ -147,7 +147,7 @@ __device__ __forceinline__ double mt_real(uint32_t y) {
 }
 
 // draws -> mask bits, one thread per (column, sub-column); the overlap rules of generate_stochastic_clouds
-// (mcica_subcol_gen_sw.f90:360-367 random, :386-393 maximum-random, :420-428 maximum) as in mt_mask_host (rrtmg_mt.cpp).
+// (mcica_subcol_gen_sw.f90:360-367 random, :386-393 maximum-random, :420-428 maximum) as in the sequential host restatement (tests/emu/mt_host_stream.cpp).
 // The stream keeps a column's draws together (layer fastest), the threads of a wavefront are 64 columns: the tile's
 // 64 x per_col draws -- one contiguous run of the stream -- are read coalesced into LDS and each lane takes its column from
 // there (row stride per_col | 1: odd, so the lanes' words sit in different banks).

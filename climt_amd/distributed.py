@@ -18,7 +18,7 @@ over torch.distributed on host memory -- the world-size-2 gloo tests on CPU, and
 
 Sharded == unsharded, bit for bit: kissvec sub-columns are seeded per column; for the Mersenne twister, whose reference stream
 is ONE sequence over (sub-column, column, layer), every rank passes its block's position (shard_col0, shard_ncol) and the
-generator skips the other ranks' draws (rrtmg_mt.cpp).  When a block boundary is not a multiple of the 64-column tile, a column
+generator starts at the rank's own draws (jump-ahead, csrc/rrtmg_mt_device.hip).  When a block boundary is not a multiple of the 64-column tile, a column
 may run the other solve-kernel variant (clear-sky / cloudy tile), which changes the shortwave by round-off only.
 """
 import ctypes as C

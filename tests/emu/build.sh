@@ -6,9 +6,10 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 OUT="$ROOT/tests/_emu"
 mkdir -p "$OUT"
+rm -f "$OUT"/*.o      # (objects of sources that have since moved must not be linked again)
 CC="hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -ffp-contract=off"
 pids=()
-for src in "$HERE/emu_sw.hip" "$HERE/emu_lw.hip" "$ROOT/climt_amd/csrc/rrtmg_tables.cpp" "$ROOT/climt_amd/csrc/rrtmg_mt.cpp"; do
+for src in "$HERE/emu_sw.hip" "$HERE/emu_lw.hip" "$ROOT/climt_amd/csrc/rrtmg_tables.cpp" "$HERE/mt_host_stream.cpp"; do
   $CC -c "$src" -o "$OUT/$(basename "$src").o" &
   pids+=($!)
 done

@@ -1,7 +1,7 @@
-// rrtmg_mt.cpp -- the reference's Mersenne-twister sub-column mask as ONE sequential stream on the host, the way the
-// reference generates it.  The library builds the same bits on the device by jump-ahead (rrtmg_mt_device.hip,
-// rrtmg_mt_jump.cpp) and does not call this; the host emulation of the tests does (tests/emu), and the device path is
-// tested bit for bit against it.
+// mt_host_stream.cpp -- TEST INFRASTRUCTURE: the reference's Mersenne-twister sub-column mask as ONE sequential stream on the
+// host, the way the reference generates it (checked against the reference Fortran's masks).  The library builds the same bits
+// on the device by jump-ahead (climt_amd/csrc/rrtmg_mt_device.hip, rrtmg_mt_jump.cpp) and contains no host generator; the host
+// emulation of the tests uses this one, and the device path is tested bit for bit against it.
 #include <cstdint>
 #include <vector>
 

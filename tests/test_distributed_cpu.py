@@ -19,7 +19,7 @@ def _free_port():
 
 def _cases():
     """(name, inputs, mcica): kissvec maximum-random, and the Mersenne twister (ONE global stream over (sub-column,
-    column, layer): sharding needs the skip-ahead of rrtmg_mt.cpp) with maximum and maximum-random overlap."""
+    column, layer): a shard has to start at its own draws -- here the host emulation's skip-ahead, on the device jump-ahead) with maximum and maximum-random overlap."""
     c1, m1, _ = load_ref_case("mcica_kiss_maxrand")
     c2, m2, _ = load_ref_case("mcica_mt_max")
     c3 = dict(c2); c3.update(icld=2, permuteseed=12345)
