@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Randomised parity sweep on the GPU box (development tool): random shapes, overlap modes, cloud / aerosol / surface options,
-McICA on and off -- the device against the live reference Fortran (oracle/_ref).  usage: tools/fuzz_parity.py [n=60] [seed=0]"""
+"""Randomised parity sweep (development tool): random shapes, overlap modes, cloud / aerosol / surface options, McICA on and off with
+either random number generator -- the device against the live reference Fortran (oracle/_ref) on the GPU box, or, with --emu, the
+host emulation of the device functions (tests/emu; small grids) against it on any machine.
+usage: tools/fuzz_parity.py [--emu] [n=60] [seed=0]"""
 import os
 import sys
 import numpy as np
@@ -12,12 +14,18 @@ def main():
     from climt_amd._lib import Context
     from climt_amd.synthetic import make_columns, overcast
     from helpers import CONSTANTS, CPDAIR, live_oracle, maxdiff
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-    ctx = Context(0); ctx.set_constants(**CONSTANTS); ctx.sw_init(CPDAIR); ctx.lw_init(CPDAIR)
+    argv = [a for a in sys.argv[1:] if a != "--emu"]
+    emu = "--emu" in sys.argv[1:]
+    n = int(argv[0]) if len(argv) > 0 else 60
+    rng = np.random.default_rng(int(argv[1]) if len(argv) > 1 else 0)
+    if emu:
+        from helpers import EmuContext
+        ctx = EmuContext()
+    else:
+        ctx = Context(0); ctx.set_constants(**CONSTANTS); ctx.sw_init(CPDAIR); ctx.lw_init(CPDAIR)
     worst = {"sw": 0.0, "lw": 0.0}
     for it in range(n):
-        ncol, nlay = int(rng.choice([1, 37, 64, 129, 300, 777])), int(rng.choice([4, 11, 30, 47, 60, 75, 100]))
+        ncol, nlay = int(rng.choice([1, 5, 19, 37] if emu else [1, 37, 64, 129, 300, 777])), int(rng.choice([4, 11, 30, 47, 60, 75, 100]))
         mcica = bool(rng.integers(0, 2))
         c = make_columns(ncol, nlay, cloudy=True, seed=int(rng.integers(1, 10 ** 6))); c.pop("lat")
         if nlay < 8:
@@ -25,7 +33,7 @@ def main():
         if not mcica:
             c = overcast(c)
         c.update(icld=int(rng.integers(0, 4)), iaer=0, adjes=1.0, dyofyr=int(rng.integers(0, 366)), scon=float(rng.choice([0.0, 1361.0])), isolvar=0,
-                 inflg=2, iceflg=int(rng.integers(1, 4)), liqflg=1, irng=0, permuteseed=int(rng.integers(1, 1024)), idrv=int(rng.integers(0, 2)))
+                 inflg=2, iceflg=int(rng.integers(1, 4)), liqflg=1, irng=int(rng.integers(0, 2)), permuteseed=int(rng.integers(1, 1024)), idrv=int(rng.integers(0, 2)))
         c["coszen"] = np.clip(c["coszen"] * rng.uniform(-0.2, 1.2, ncol), -0.1, 1.0)      # night columns too
         c["emis"] = rng.uniform(0.85, 1.0, (16, ncol))
         opt = rng.integers(0, 4)
@@ -51,8 +59,8 @@ def main():
         dsw = max(maxdiff(gsw[k], rsw[k]) for k in rsw); dlw = max(maxdiff(glw[k], rlw[k]) for k in rlw)
         worst["sw"], worst["lw"] = max(worst["sw"], dsw), max(worst["lw"], dlw)
         flag = "" if dsw < 1e-6 and dlw < 1e-7 else "   <<<<<<"
-        print("%3d %s ncol %4d nlay %3d mcica %d icld %d opt %d ice %d/%d liq %d idrv %d  |d| sw %.2e lw %.2e%s" % (
-            it, kind, ncol, nlay, mcica, c["icld"], opt, c["iceflg"], lw_in["iceflg"], lw_in["liqflg"], c["idrv"], dsw, dlw, flag), flush=True)
+        print("%3d %s ncol %4d nlay %3d mcica %d rng %d icld %d opt %d ice %d/%d liq %d idrv %d  |d| sw %.2e lw %.2e%s" % (
+            it, kind, ncol, nlay, mcica, c["irng"], c["icld"], opt, c["iceflg"], lw_in["iceflg"], lw_in["liqflg"], c["idrv"], dsw, dlw, flag), flush=True)
     print("worst:", worst)
 
 
