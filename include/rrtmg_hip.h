@@ -191,8 +191,8 @@ typedef struct rrtmg_sw_args {
   const double *tauaer, *ssaaer, *asmaer;            /* [14][nlay][ncol] */
   const double *ecaer;                               /* [6][nlay][ncol]  */
   /* McICA: optional externally generated sub-column cloud mask, [nlay][ncol][112] of 0.0/1.0
-   * (e.g. cldfmcl from mcica_subcol_sw_wrapper). NULL -> generated on the device (kissvec)
-   * or on the host and uploaded (Mersenne twister). */
+   * (e.g. cldfmcl from mcica_subcol_sw_wrapper). NULL -> generated on the device by either
+   * generator (irng 0 kissvec, 1 Mersenne twister: its one stream by jump-ahead). */
   const double *cldfmcl;
   /* outputs */
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
