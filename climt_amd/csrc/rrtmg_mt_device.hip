@@ -4,12 +4,12 @@
 // (mcica_random_numbers.f90:77-302, mcica_subcol_gen_sw.f90:360-428).  Generated on the host it cost 0.4-0.5 s per spectrum at
 // 8192 columns x 60 layers -- a hundred times the radiation itself -- and every rank of a sharded run had to walk through the
 // draws of all the others.  Here the stream is cut into segments -- the draws of this call's columns for one sub-column are
-// contiguous: one run per sub-column, each run in a few pieces of ~128 K draws -- every segment's 624-word window is formed by
-// polynomial jump-ahead (rrtmg_mt_jump.cpp) from the 20 561 words that follow the seed, and one wavefront per segment runs the
+// contiguous: one run per sub-column, a large run in pieces of ~256 K draws -- every segment's 624-word window is formed by
+// polynomial jump-ahead (rrtmg_mt_jump.cpp) from the 20 561 words that follow the seed, and one workgroup per segment runs the
 // recurrence from there:
-//   mt_seed_kernel    <<<1, 64>>>        the seed's initial window and the words behind it, x[0 .. kMtBase)
+//   mt_seed_kernel    <<<1, 256>>>       the seed's initial window and the words behind it, x[0 .. kMtBase)
 //   mt_jump_kernel    <<<segments, 640>>> window of segment k = XOR over the terms t^i of its polynomial of x[1 + i ..]
-//   mt_stream_kernel  <<<segments, 64>>>  the segment's tempered 32-bit draws, in stream order, to HBM
+//   mt_stream_kernel  <<<segments, 256>>> the segment's tempered 32-bit draws, in stream order, to HBM
 //   mt_mask_kernel    <<<(sub-columns, tiles), 64>>>  draws -> cloud-mask bits, one thread per (column, sub-column), with the
 //                     reference's conversion to a real number and its overlap rules
 // Same bits as the sequential stream (GPU test against the host generator the reference masks were checked with).
@@ -39,68 +39,61 @@ __device__ __forceinline__ uint32_t mt_temper(uint32_t y) {
   return y;
 }
 
-// One wavefront replaces the window st[0 .. 624) (LDS) by the next 624 words, in place, as nextState does
-// (mcica_random_numbers.f90:97-121).  Word k needs the OLD k and k + 1 and, for k < 227, the old k + 397, for k >= 227 the NEW
-// k - 227 (k = 623: the new word 0 as its neighbour) -- so the words fall into three runs, [0, 227), [227, 454), [454, 624),
-// inside which nothing depends on anything written in the same run: every lane reads its (up to four) words of a run, then all
-// write.  Three read / write rounds per 624 draws.  The workgroup IS one wavefront, whose LDS instructions execute in the
-// order they were issued for all 64 lanes at once: a round's writes follow its reads and precede the next round's reads
-// without a barrier (the compiler keeps the order: every access goes to the same array at an index it cannot tell apart).
-// out != nullptr: the tempered words go to out[0 .. limit) as they are formed.
+// A workgroup of kMtGenThreads = 256 threads replaces the window st[0 .. 624) (LDS) by the next 624 words, in place, as
+// nextState does (mcica_random_numbers.f90:97-121).  Word k needs the OLD k and k + 1 and, for k < 227, the old k + 397, for
+// k >= 227 the NEW k - 227 (k = 623: the new word 0 as its neighbour) -- so the words fall into three runs, [0, 227),
+// [227, 454), [454, 624), inside which nothing depends on anything written in the same run: one word per thread, every thread
+// reads, barrier, every thread writes, barrier.  Three such rounds per 624 draws (one wavefront doing four words per lane took
+// 3000 cycles per window: the rounds' LDS round trips in a row, nothing else resident to fill them).
+// OUT: the tempered words go to out[0 .. limit) as they are formed.
+constexpr int kMtGenThreads = 256;
 template <bool OUT>
-__device__ __forceinline__ void mt_next_block(uint32_t *st, int lane, uint32_t *out, long limit) {
+__device__ __forceinline__ void mt_next_block(uint32_t *st, int tid, uint32_t *out, long limit) {
   constexpr int kRun = kMtN - kMtM;   // 227
-  uint32_t v[4];
 #pragma unroll
   for (int run = 0; run < 3; ++run) {
     const int lo = run * kRun, hi = run == 2 ? kMtN : lo + kRun;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = lo + lane + 64 * i;
-      if (k < hi) {
-        const uint32_t c = run == 0 ? st[k + kMtM] : st[k - kRun];
-        v[i] = c ^ mt_twist(st[k], st[k + 1 < kMtN ? k + 1 : 0]);
-      }
+    const int k = lo + tid;
+    uint32_t v = 0;
+    if (k < hi) {
+      const uint32_t c = run == 0 ? st[k + kMtM] : st[k - kRun];
+      v = c ^ mt_twist(st[k], st[k + 1 < kMtN ? k + 1 : 0]);
     }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int k = lo + lane + 64 * i;
-      if (k < hi) {
-        st[k] = v[i];
-        if (OUT && k < limit) out[k] = mt_temper(v[i]);
-      }
+    __syncthreads();
+    if (k < hi) {
+      st[k] = v;
+      if (OUT && k < limit) out[k] = mt_temper(v);
     }
-    __builtin_amdgcn_wave_barrier();
+    __syncthreads();
   }
 }
 
-__global__ void __launch_bounds__(64) mt_seed_kernel(uint32_t seed, uint32_t *x) {
+__global__ void __launch_bounds__(kMtGenThreads) mt_seed_kernel(uint32_t seed, uint32_t *x) {
   __shared__ uint32_t st[kMtN];
-  const int lane = threadIdx.x;
-  if (lane == 0) {
+  const int tid = threadIdx.x;
+  if (tid == 0) {
     uint32_t v = seed;
     st[0] = v;
     for (int i = 1; i < kMtN; ++i) { v = 1812433253u * (v ^ (v >> 30)) + (uint32_t)i; st[i] = v; }   // initialize_scalar, :139-150
   }
   __syncthreads();
-  for (int i = lane; i < kMtN; i += 64) x[i] = st[i];
+  for (int i = tid; i < kMtN; i += kMtGenThreads) x[i] = st[i];
   for (int base = kMtN; base < kMtBase; base += kMtN) {
-    mt_next_block<false>(st, lane, nullptr, 0);
-    __syncthreads();
-    for (int i = lane; i < kMtN && base + i < kMtBase; i += 64) x[base + i] = st[i];
+    mt_next_block<false>(st, tid, nullptr, 0);
+    for (int i = tid; i < kMtN && base + i < kMtBase; i += kMtGenThreads) x[base + i] = st[i];
     __syncthreads();
   }
 }
 
 // window[k][j] = x[n_k + j]: for a segment that starts at draw 0 (count -1) the seed's own window, else the jump.  The
-// polynomial arrives as the list of its exponents (workgroup-uniform reads): eight terms' words are fetched before they are
-// folded in, so the fetches overlap; the list itself is staged in LDS first (fetched from memory eight at a time it cost a
-// round trip per eight terms, and a loop over the bits of the polynomial serialised on every fetch: 0.6 ms per workgroup either way).
-constexpr int kMtJumpThreads = 640;   // ten wavefronts, one window word each
+// polynomial arrives as the list of its exponents: the same for every lane and written by nothing in this kernel, so they come
+// through the scalar cache, 16 at a time, and the words of 16 terms are in flight together.  Ten wavefronts, one window word
+// per lane: the LDS copy of x allows one workgroup per CU, and a wavefront has at most 15 LDS reads outstanding -- it takes
+// that many wavefronts to keep the LDS busy (three wavefronts folding four words per lane: 0.38 ms per workgroup instead of 0.24).
+constexpr int kMtJumpThreads = 640;
 __global__ void __launch_bounds__(kMtJumpThreads) mt_jump_kernel(const uint32_t *__restrict__ x, const uint32_t *__restrict__ lists,
                                                                const int32_t *__restrict__ counts, uint32_t *__restrict__ windows) {
-  extern __shared__ uint32_t xs[];                // kMtXs words of the seed's stream
+  extern __shared__ uint32_t xs[];                // kMtXs words of the seed's stream (zeros behind x[kMtBase))
   const int k = blockIdx.x;
   const int n = counts[k];
   for (int i = threadIdx.x; i < kMtXs; i += kMtJumpThreads) xs[i] = i < kMtBase ? x[i] : 0u;
@@ -111,8 +104,6 @@ __global__ void __launch_bounds__(kMtJumpThreads) mt_jump_kernel(const uint32_t 
     if (threadIdx.x < kMtN) w[j] = xs[j];
     return;
   }
-  // the exponents are the same for every lane and nothing in this kernel writes them: scalar loads, 16 at a time, the words
-  // of 16 terms in flight together
   const uint32_t *__restrict__ L = lists + (long)k * kMtListMax;
   const uint32_t *xj = xs + 1 + j;
   uint32_t a = 0;
@@ -128,15 +119,15 @@ __global__ void __launch_bounds__(kMtJumpThreads) mt_jump_kernel(const uint32_t 
 
 // the tempered draws of segment k = (run g, piece sidx): out[g * count + sidx * piece ..], `piece` of them (the run's last piece:
 // what is left of its `count`)
-__global__ void __launch_bounds__(64) mt_stream_kernel(const uint32_t *windows, long count, long piece, int npiece, uint32_t *out) {
+__global__ void __launch_bounds__(kMtGenThreads) mt_stream_kernel(const uint32_t *windows, long count, long piece, int npiece, uint32_t *out) {
   __shared__ uint32_t st[kMtN];
-  const int lane = threadIdx.x, k = blockIdx.x, g = k / npiece, sidx = k % npiece;
-  for (int i = lane; i < kMtN; i += 64) st[i] = windows[(long)k * kMtN + i];
+  const int tid = threadIdx.x, k = blockIdx.x, g = k / npiece, sidx = k % npiece;
+  for (int i = tid; i < kMtN; i += kMtGenThreads) st[i] = windows[(long)k * kMtN + i];
   __syncthreads();
   const long begin = (long)sidx * piece;
   const long len = count - begin < piece ? count - begin : piece;
   uint32_t *o = out + (long)g * count + begin;
-  for (long base = 0; base < len; base += kMtN) mt_next_block<true>(st, lane, o + base, len - base);
+  for (long base = 0; base < len; base += kMtN) mt_next_block<true>(st, tid, o + base, len - base);
 }
 
 // getRandomReal (mcica_random_numbers.f90:282-296): a negative localInt goes through DEFAULT-real (single precision) arithmetic
@@ -195,8 +186,8 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
   const uint64_t ncolT = ncol_total > 0 ? (uint64_t)ncol_total : (uint64_t)ncol;
   const uint64_t first = (ncol_total > 0 ? (uint64_t)col0 : 0) * per_col, stride = ncolT * per_col;
   const long count = (long)ncol * (long)per_col;
-  // pieces of ~128 K draws (200 regenerations of the window: 0.2 ms for the wavefront that runs them), at most ~1000 segments
-  int npiece = (int)((count + 131071) / 131072);
+  // pieces of ~256 K draws (400 regenerations of the window: 0.2 ms for the workgroup that runs them), at most ~1000 segments
+  int npiece = (int)((count + 262143) / 262144);
   if (npiece > 1024 / nsub) npiece = 1024 / nsub;
   if (npiece < 1) npiece = 1;
   const long piece = (count + npiece - 1) / npiece;
@@ -224,9 +215,9 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
   const size_t mask_lds = (size_t)64 * ((icld == 3 ? 1 : nlay) | 1) * 4;   // (256 layers: 64.25 KB, just over what a kernel may have unasked)
   static const bool mask_lds_ok = hipFuncSetAttribute((const void *)mt_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4) == hipSuccess;
   if (mask_lds > 64 * 1024 && !mask_lds_ok) return ctx->fail(RRTMG_ERR_HIP, "mt_mask_kernel: %zu bytes of dynamic LDS refused", mask_lds);
-  hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(64), 0, s, (uint32_t)seed, x);
+  hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(kMtGenThreads), 0, s, (uint32_t)seed, x);
   hipLaunchKernelGGL(mt_jump_kernel, dim3(nseg), dim3(kMtJumpThreads), (size_t)kMtJumpLds, s, x, lists, counts, win);
-  hipLaunchKernelGGL(mt_stream_kernel, dim3(nseg), dim3(64), 0, s, win, count, piece, npiece, draws);
+  hipLaunchKernelGGL(mt_stream_kernel, dim3(nseg), dim3(kMtGenThreads), 0, s, win, count, piece, npiece, draws);
   hipLaunchKernelGGL(mt_mask_kernel, dim3(nsub, (ncol + 63) / 64), dim3(64), mask_lds, s, ncol, nlay, icld, cldfr, draws, mask, nw);
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
   return RRTMG_OK;

@@ -9,8 +9,8 @@ import climt_amd
 from climt_amd import _hip
 
 
-def loop(device, steps, mcica=False, wait=False):
-    kw = dict(mcica=True, random_number_generator="kissvec") if mcica else {}
+def loop(device, steps, mcica=False, wait=False, rng="kissvec"):
+    kw = dict(mcica=True, random_number_generator=rng) if mcica else {}
     sun, slab = climt_amd.Instellation(), climt_amd.SlabSurface()
     lw, sw = climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **kw), climt_amd.RRTMGShortwave(**kw)
     state = climt_amd.get_default_state([sun, lw, sw, slab], grid_state=climt_amd.get_grid(nx=128, ny=64, nz=60))
@@ -44,6 +44,8 @@ if __name__ == "__main__":
         dw = loop(True, 200, mc, wait=True)
         h = loop(False, 5, mc)
         print("mcica=%d  device-resident %.3f ms/step (%.3g columns/s; %.3f ms with a host wait per step)   host state %.1f ms/step" % (mc, d, 8192 / (d * 1e-3), dw, h))
+    d = loop(True, 200, True, rng="mersenne_twister")
+    print("mcica=1 with the reference's default generator (mersenne_twister): device-resident %.3f ms/step" % d)
     if len(sys.argv) > 1 and sys.argv[1] == "profile":
         import cProfile, pstats
         pr = cProfile.Profile(); pr.enable()
