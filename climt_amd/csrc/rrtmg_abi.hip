@@ -53,11 +53,13 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host) {
   // A destination that is page-locked memory the runtime knows (hipHostMalloc / hipHostRegister: the components' output pool
   // hands such arrays out) takes its copy directly; the others go through the staging buffer.
-  bool direct[16];
+  constexpr int kMaxOut = 16;
+  if (count > kMaxOut) return ctx->fail(RRTMG_ERR_ARG, "copy_out: %d output arrays (at most %d)", count, kMaxOut);
+  bool direct[kMaxOut];
   size_t total = 0;
   for (int i = 0; i < count; ++i) {
     hipPointerAttribute_t at;
-    direct[i] = i < 16 && hipPointerGetAttributes(&at, o[i].host) == hipSuccess && at.type == hipMemoryTypeHost;
+    direct[i] = hipPointerGetAttributes(&at, o[i].host) == hipSuccess && at.type == hipMemoryTypeHost;
     if (!direct[i]) total += o[i].n * sizeof(double);
   }
   (void)hipGetLastError();   // (an unknown pointer is an error code of the query, not of this call)

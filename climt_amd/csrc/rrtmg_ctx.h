@@ -54,6 +54,14 @@ struct rrtmg_ctx {
   // Mersenne-twister jump polynomials [sw|lw] on the device: the (first draw, stride, runs, piece, pieces) they were built for
   uint64_t mt_key[2][5] = {{~0ull, ~0ull, ~0ull, ~0ull, ~0ull}, {~0ull, ~0ull, ~0ull, ~0ull, ~0ull}};
   const void *mt_dev[2] = {nullptr, nullptr};
+  // hipFuncSetAttribute(MaxDynamicSharedMemorySize) holds per DEVICE (a kernel's code object is loaded once per device): a
+  // context belongs to one device, so every context asks once -- after ctx_prepare_device has made its device current --
+  // and keeps the answer.  [0] lw_prep_fused_kernel, [1] mt_jump_kernel, [2] mt_mask_kernel; -1 = not asked yet
+  int big_lds[3] = {-1, -1, -1};
+  bool allow_dynamic_lds(int slot, const void *kernel, int bytes) {
+    if (big_lds[slot] < 0) big_lds[slot] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 0;
+    return big_lds[slot] > 0;
+  }
   std::string err;
   int status = 0;
   rrtmg::Constants k{};

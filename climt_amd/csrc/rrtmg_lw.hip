@@ -306,8 +306,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     d.tlev = tl;
   }
   // (more than 64 KB of dynamic LDS has to be allowed per kernel once; if the runtime refuses, the scan re-reads the slab)
-  static const bool big_lds = hipFuncSetAttribute((const void *)lw_prep_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  kLwKeepLayers * 3 * 64 * (int)sizeof(double)) == hipSuccess;
+  const bool big_lds = ctx->allow_dynamic_lds(0, (const void *)lw_prep_fused_kernel, kLwKeepLayers * 3 * 64 * (int)sizeof(double));
   const int keep_layers = (L <= kLwKeepLayers && (big_lds || (size_t)L * 3 * 64 * sizeof(double) <= 64 * 1024)) ? L : 0;
   if (clouds) {
     if (d.mcica) {

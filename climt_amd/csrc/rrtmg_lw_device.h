@@ -904,10 +904,9 @@ RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
   return p[0] + frac * (p[1] - p[0]);
 }
 
-// Scratch rows per (layer, item).  0 = 1: ONE row, the gas optical depth of every (layer, g-point) cell; the
-// upward sweep forms transmittance and source terms again from it (lw_cell) with the layer's Planck terms and Planck
-// fractions recomputed -- half the scratch slab in cloud-free layers, a quarter in cloudy ones.  0: atrans and bbugas
-// (+ atot, bbutot in cloudy layers) as computed by the downward sweep.
+// Scratch rows per (layer, item): atrans and bbugas (+ atot, bbutot in cloudy layers) as computed by the downward sweep,
+// read back by the upward sweep.  (Keeping only the gas optical depth and re-forming the terms going up halves the slab
+// and was measured 14 % slower: DESIGN.md 5.)
 enum { LF_ATRANS = 0, LF_BBUGAS, LF_ATOT, LF_BBUTOT, LF_N };
 
 // Per-item radiance sink (host emulation, tests and the device kernel): the band-weighted radiances, summed over
@@ -938,13 +937,12 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
   return s;
 }
 
-// quotient of the Pade table index x/(bpade + x): 0=1 uses the quick division (see qdiv)
+// quotient of the Pade table index x/(bpade + x): the IEEE division (the index decides which table entry is read)
 #define LW_TDIV(a, b) ((a) / (b))
 #define LW_TBLIDX(x) ((int)(x))
 // Transmittance and Planck source terms of ONE (layer, g-point) cell from its gas optical depth (already times the
-// diffusivity angle, clamped at zero) -- rrtmg_lw_rtrn.f90:342-447 / rrtmg_lw_rtrnmc.f90:342-456.  Both sweeps call it with
-// the same arguments: the downward sweep keeps only the optical depth of every cell (one scratch value instead of
-// atrans + bbugas, + atot + bbutot in cloudy layers), the upward sweep forms its terms again from it.
+// diffusivity angle, clamped at zero) -- rrtmg_lw_rtrn.f90:342-447 / rrtmg_lw_rtrnmc.f90:342-456.  Called by the downward
+// sweep only; the upward sweep reads the terms back from the scratch rows (LF_*).
 struct LwLut { const double *exp_tbl, *tau_tbl, *tfn_tbl; };
 struct LwCell { double atrans, bbd, bbugas, gassrc, atot, bbdtot, bbutot; };
 // The G cells of one layer at once, WITHOUT data-dependent branches around the table lookups: the reference's

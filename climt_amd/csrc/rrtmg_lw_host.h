@@ -86,8 +86,8 @@ inline bool build_lw_tab(TableSet &ts, LwTab &T, std::string &err) {
   for (int b = 0; b < kLwNBand; ++b) {
     int ig = 0;
     while (ig < T.b[b].ng) {
-      // (0: the bands without a binary species mixture -- few table rows, little layer state -- in chunks of 8)
-      const int g = (0 && nspa[b] == 1 && T.b[b].ng - ig >= 8) ? 8 : (T.b[b].ng - ig >= 4 && 4 >= 4) ? 4 : 2;
+      // (chunks of 8 for the bands without a binary species mixture were measured slower: DESIGN.md 5)
+      const int g = T.b[b].ng - ig >= 4 ? 4 : 2;
       if ((long)T.b[b].nrows * g > (long)kLwSlabMaxRows * 4) { err = "work item slice does not fit the LDS buffer"; return false; }
       if (T.nitem >= kLwMaxItem) { err = "too many work items"; return false; }
       cost[T.nitem] = (nspa[b] == 9 ? 2.0 : 1.0) + g * 0.7;

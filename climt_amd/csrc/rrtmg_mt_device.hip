@@ -210,10 +210,10 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
     RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));   // (the host vectors go out of scope)
     key[0] = first; key[1] = stride; key[2] = (uint64_t)nsub; key[3] = (uint64_t)piece; key[4] = (uint64_t)npiece; ctx->mt_dev[which] = lists;
   }
-  static const bool big_lds = hipFuncSetAttribute((const void *)mt_jump_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMtJumpLds) == hipSuccess;
+  const bool big_lds = ctx->allow_dynamic_lds(1, (const void *)mt_jump_kernel, kMtJumpLds);
   if (!big_lds) return ctx->fail(RRTMG_ERR_HIP, "mt_jump_kernel: %d bytes of dynamic LDS refused", kMtJumpLds);
   const size_t mask_lds = (size_t)64 * ((icld == 3 ? 1 : nlay) | 1) * 4;   // (256 layers: 64.25 KB, just over what a kernel may have unasked)
-  static const bool mask_lds_ok = hipFuncSetAttribute((const void *)mt_mask_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 257 * 4) == hipSuccess;
+  const bool mask_lds_ok = ctx->allow_dynamic_lds(2, (const void *)mt_mask_kernel, 64 * 257 * 4);
   if (mask_lds > 64 * 1024 && !mask_lds_ok) return ctx->fail(RRTMG_ERR_HIP, "mt_mask_kernel: %zu bytes of dynamic LDS refused", mask_lds);
   hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(kMtGenThreads), 0, s, (uint32_t)seed, x);
   hipLaunchKernelGGL(mt_jump_kernel, dim3(nseg), dim3(kMtJumpThreads), (size_t)kMtJumpLds, s, x, lists, counts, win);

@@ -167,10 +167,10 @@ class RRTMGLongwave(TendencyComponent):
             dflxc=diagnostics["downwelling_longwave_flux_in_air_assuming_clear_sky"],
             hrc=diagnostics["air_temperature_tendency_from_longwave_assuming_clear_sky"])
         if self._calc_dflxdt:
-            # (computed, not returned -- as in the reference, lw/component.py:386-399 -- so the two arrays are kept between calls:
-            #  fresh ones cost their first-touch page faults on every call)
-            out["duflx_dt"] = self._input_staging.array("duflx_dt", (n_layers + 1, n_columns))
-            out["duflxc_dt"] = self._input_staging.array("duflxc_dt", (n_layers + 1, n_columns))
+            # (computed, not returned -- as in the reference, lw/component.py:386-399.  From the liveness-tracked output pool,
+            #  like every other result: an array the caller still holds from an earlier call is never written again)
+            for key in ("duflx_dt", "duflxc_dt"):
+                out[key] = self._pool.zeros_like_fresh(key, (n_layers + 1, n_columns))
         self._input_staging.wait()
         self._ctx.lw_fluxes(inp, mcica=self._mcica, out=out)
         if self._calc_dflxdt:

@@ -349,7 +349,206 @@ def cache_outputs_only(cls, desc):
     np.savez_compressed(os.path.join(OUT, "climt_cacheout_%s-%s.npz" % (cls, desc)), **save)
     print("cache outputs", cls, desc, len(save))
 
+
+# ---- the longwave drop-in CLASS: values a user of RRTMGLongwave()(state) gets ----------------------------------------------
+# An independent numpy restatement of what happens between a sympl state and the reference binder's argument list
+# (sympl's extraction: units + dim order, climt/_components/rrtmg/lw/component.py:374-447, climt/_core/util.py:47-142,
+# _rrtmg_lw.pyx:137-282), feeding the reference Fortran (oracle/_ref; SYNTHETIC k-tables while rrtmg_lw_k_g.f90 is a missing
+# blob).  Nothing of climt_amd's host layer (_sympl_compat, rrtmg/longwave.py, _util.py) is used here: the fixtures pin it.
+_LW_CLASS_INPUTS = {   # name -> (target dims, factor from the cached state's units to the component's units)
+    "air_pressure": (("mid_levels", "*"), {"Pa": 0.01, "mbar": 1.0}),
+    "air_pressure_on_interface_levels": (("interface_levels", "*"), {"Pa": 0.01, "mbar": 1.0}),
+    "air_temperature": (("mid_levels", "*"), {"degK": 1.0}),
+    "air_temperature_on_interface_levels": (("interface_levels", "*"), {"degK": 1.0}),
+    "surface_temperature": (("*",), {"degK": 1.0}),
+    "specific_humidity": (("mid_levels", "*"), {"dimensionless": 1.0, "g/g": 1.0, "kg/kg": 1.0}),
+    "surface_longwave_emissivity": (("num_longwave_bands", "*"), {"dimensionless": 1.0}),
+    "cloud_area_fraction_in_atmosphere_layer": (("mid_levels", "*"), {"dimensionless": 1.0}),
+    "longwave_optical_thickness_due_to_cloud": (("mid_levels", "*", "num_longwave_bands"), {"dimensionless": 1.0}),
+    "mass_content_of_cloud_ice_in_atmosphere_layer": (("mid_levels", "*"), {"kg/m**2": 1000.0, "kg m^-2": 1000.0, "g m^-2": 1.0}),
+    "mass_content_of_cloud_liquid_water_in_atmosphere_layer": (("mid_levels", "*"), {"kg/m**2": 1000.0, "kg m^-2": 1000.0, "g m^-2": 1.0}),
+    "cloud_ice_particle_size": (("mid_levels", "*"), {"µm": 1.0, "micrometer": 1.0}),
+    "cloud_water_droplet_radius": (("mid_levels", "*"), {"µm": 1.0, "micrometer": 1.0}),
+    "longwave_optical_thickness_due_to_aerosol": (("num_longwave_bands", "mid_levels", "*"), {"dimensionless": 1.0}),
+}
+for _gas in ("ozone", "carbon_dioxide", "methane", "nitrous_oxide", "oxygen", "cfc11", "cfc12", "cfc22", "carbon_tetrachloride"):
+    _LW_CLASS_INPUTS["mole_fraction_of_%s_in_air" % _gas] = (("mid_levels", "*"), {"dimensionless": 1.0})
+_LW_OVERLAP = {"clear_only": 0, "random": 1, "maximum_random": 2, "maximum": 3}           # rrtmg_common.py:8-13
+_LW_CLOUD_PROPS = {"direct_input": 0, "single_cloud_type": 1, "liquid_and_ice_clouds": 2}     # :20-24
+_LW_ICE = {"ebert_curry_one": 0, "ebert_curry_two": 1, "key_streamer_manual": 2, "fu": 3}    # :31-36
+_LW_LIQ = {"radius_independent_absorption": 0, "radius_dependent_absorption": 1}             # :43-46
+
+
+def lw_class_reference(state, kwargs, lw):
+    """state: {name: (values, dims, units)}; kwargs: RRTMGLongwave's constructor arguments -> ({group: {name: (values, dims,
+    units)}}) as the reference class would return it, computed by the reference Fortran `lw` (an initialised RefLW)."""
+    named = ("mid_levels", "interface_levels", "num_longwave_bands")
+    wild = [d for d in state["air_pressure"][1] if d not in named]            # sympl: wildcard dims in order of first appearance
+    wshape = tuple(state["air_pressure"][0].shape[state["air_pressure"][1].index(d)] for d in wild)
+    raw = {}
+    for name, (target, factors) in _LW_CLASS_INPUTS.items():
+        if name not in state:
+            continue
+        v, dims, units = state[name]
+        order = []
+        for t in target:
+            order += [dims.index(d) for d in wild] if t == "*" else [dims.index(t)]
+        a = np.transpose(np.asarray(v, dtype=np.float64), order)
+        # (the named dims keep their lengths; the wildcard dims collapse, C order, into the column index)
+        shp, i = [], 0
+        for t in target:
+            if t == "*":
+                shp.append(int(np.prod(wshape))); i += len(wild)
+            else:
+                shp.append(a.shape[i]); i += 1
+        raw[name] = np.ascontiguousarray(a.reshape(shp) * factors[units])
+    p, pi, t = raw["air_pressure"], raw["air_pressure_on_interface_levels"], raw["air_temperature"]
+    nlay, ncol = t.shape
+    if kwargs.get("calculate_interface_temperature", True):
+        # climt/_core/util.py:89-142, restated
+        tint = np.zeros((nlay + 1, ncol))
+        lp = np.log(p)
+        w = (np.log(pi[1:-1]) - lp[1:]) / (lp[:-1] - lp[1:])
+        tint[1:-1] = t[1:] - w * (t[1:] - t[:-1])
+        tint[0] = raw["surface_temperature"]
+        tint[-1] = t[-1]
+    else:
+        tint = raw["air_temperature_on_interface_levels"]
+    mcica = bool(kwargs.get("mcica", False))
+    overlap = kwargs.get("cloud_overlap_method") or "random"                          # lw/component.py:296-297
+    c = dict(play=p, plev=pi, tlay=t, tlev=tint, tsfc=raw["surface_temperature"],
+             h2o=raw["specific_humidity"] * 28.964 / 18.02,                           # util.py:86
+             o3=raw["mole_fraction_of_ozone_in_air"], co2=raw["mole_fraction_of_carbon_dioxide_in_air"],
+             ch4=raw["mole_fraction_of_methane_in_air"], n2o=raw["mole_fraction_of_nitrous_oxide_in_air"],
+             o2=raw["mole_fraction_of_oxygen_in_air"], cfc11=raw["mole_fraction_of_cfc11_in_air"],
+             cfc12=raw["mole_fraction_of_cfc12_in_air"], cfc22=raw["mole_fraction_of_cfc22_in_air"],
+             ccl4=raw["mole_fraction_of_carbon_tetrachloride_in_air"], emis=raw["surface_longwave_emissivity"],
+             cldfr=raw["cloud_area_fraction_in_atmosphere_layer"], taucld=raw["longwave_optical_thickness_due_to_cloud"],
+             cicewp=raw["mass_content_of_cloud_ice_in_atmosphere_layer"],
+             cliqwp=raw["mass_content_of_cloud_liquid_water_in_atmosphere_layer"],
+             reice=raw["cloud_ice_particle_size"], reliq=raw["cloud_water_droplet_radius"],
+             tauaer=raw["longwave_optical_thickness_due_to_aerosol"],
+             icld=_LW_OVERLAP[overlap.lower()], idrv=0,
+             inflg=_LW_CLOUD_PROPS[kwargs.get("cloud_optical_properties", "liquid_and_ice_clouds").lower()],
+             iceflg=_LW_ICE[kwargs.get("cloud_ice_properties", "ebert_curry_two").lower()],
+             liqflg=_LW_LIQ[kwargs.get("cloud_liquid_water_properties", "radius_dependent_absorption").lower()])
+    if mcica:
+        # the seed drawn per call (lw/component.py:415-424) after the reference tests' np.random.seed(0) (test_components.py:148)
+        np.random.seed(0)
+        irng = {"kissvec": 0, "mersenne_twister": 1}[kwargs.get("random_number_generator", "mersenne_twister").lower()]
+        c.update(irng=irng, permuteseed=int(np.random.randint(0, 1024) if irng == 0 else np.random.randint(0, 2 ** 31 - 1)))
+    r = lw.fluxes(c, mcica=mcica)
+    il, ml = ("interface_levels",) + tuple(wild), ("mid_levels",) + tuple(wild)
+    back = lambda a: np.ascontiguousarray(a.reshape((a.shape[0],) + wshape))
+    diag = {"upwelling_longwave_flux_in_air": (back(r["uflx"]), il, "W m^-2"),
+            "downwelling_longwave_flux_in_air": (back(r["dflx"]), il, "W m^-2"),
+            "upwelling_longwave_flux_in_air_assuming_clear_sky": (back(r["uflxc"]), il, "W m^-2"),
+            "downwelling_longwave_flux_in_air_assuming_clear_sky": (back(r["dflxc"]), il, "W m^-2"),
+            "air_temperature_tendency_from_longwave_assuming_clear_sky": (back(r["hrc"]), ml, "degK day^-1"),
+            "air_temperature_tendency_from_longwave": (back(r["hr"]), ml, "degK day^-1")}      # alias, lw/component.py:518-520
+    return {"tend": {"air_temperature": (back(r["hr"]), ml, "degK day^-1")}, "diag": diag}, c
+
+
+def _lw_class_perturbed_states():
+    """States that a wrong axis, a wrong unit factor or a wrong flag cannot survive: every optional longwave input is
+    non-trivial and differs along every axis (the reference's default states have emissivity 1, no aerosol, no cloud optical
+    depth, q = 0).  Built on the grid of the TestRRTMGLongwaveMCICA 3-d cache state (5 x 10 x 28)."""
+    import json
+    z = np.load(os.path.join(OUT, "climt_cache_TestRRTMGLongwaveMCICA-3d.npz"))
+    base = {k.split("/")[1]: (z[k], tuple(str(z[k[:-6] + "dims"]).split(",")), str(z[k[:-6] + "units"]))
+            for k in z.files if k.startswith("state/") and k.endswith("/values")}
+    rng = np.random.default_rng(20260928)
+    L, ny, nx = base["air_temperature"][0].shape
+    def put(st, name, v):
+        st[name] = (np.ascontiguousarray(v), st[name][1], st[name][2])
+    def common(st):
+        p = st["air_pressure"][0]
+        t = np.maximum(288.0 * (p / p[0]) ** 0.19 + rng.uniform(-3, 3, p.shape), 205.0)
+        put(st, "air_temperature", t)
+        put(st, "surface_temperature", t[0] + rng.uniform(-2.0, 6.0, (ny, nx)))
+        put(st, "specific_humidity", np.maximum(3e-6, 0.012 * (p / p[0]) ** 3 * rng.uniform(0.5, 1.0, p.shape)))
+        put(st, "mole_fraction_of_methane_in_air", np.full(p.shape, 1.7e-6) * rng.uniform(0.9, 1.1, p.shape))
+        put(st, "mole_fraction_of_nitrous_oxide_in_air", np.full(p.shape, 3.0e-7) * rng.uniform(0.9, 1.1, p.shape))
+        for gas, ppb in (("cfc11", 0.25), ("cfc12", 0.5), ("cfc22", 0.1), ("carbon_tetrachloride", 0.1)):
+            put(st, "mole_fraction_of_%s_in_air" % gas, np.full(p.shape, ppb * 1e-9) * rng.uniform(0.8, 1.2, p.shape))
+        put(st, "surface_longwave_emissivity", rng.uniform(0.85, 1.0, (16, ny, nx)))
+        prof = np.exp(-np.arange(L) / 5.0)[None, :, None, None]
+        put(st, "longwave_optical_thickness_due_to_aerosol", rng.uniform(0.0, 0.06, (16, L, ny, nx)) * prof)
+        f = np.zeros((L, ny, nx))
+        f[6:12] = rng.choice([0.0, 0.25, 0.5, 1.0], (6, ny, nx))
+        f[15:19] = rng.uniform(0.05, 0.9, (4, ny, nx)) * (rng.uniform(0, 1, (4, ny, nx)) > 0.3)
+        put(st, "cloud_area_fraction_in_atmosphere_layer", f)
+        put(st, "mass_content_of_cloud_liquid_water_in_atmosphere_layer", np.where((f > 0) & (t > 253.0), rng.uniform(0.02, 0.08, f.shape), 0.0))
+        put(st, "mass_content_of_cloud_ice_in_atmosphere_layer", np.where((f > 0) & (t < 263.0), rng.uniform(0.005, 0.03, f.shape), 0.0))
+        put(st, "cloud_ice_particle_size", rng.uniform(15.0, 120.0, f.shape))
+        put(st, "cloud_water_droplet_radius", rng.uniform(4.0, 40.0, f.shape))
+        put(st, "longwave_optical_thickness_due_to_cloud", rng.uniform(0.2, 5.0, (L, ny, nx, 16)) * (f > 0)[..., None])
+        return st
+    cases = {}
+    cases["direct_input_random"] = (common(dict(base)), dict(cloud_optical_properties="direct_input", cloud_overlap_method="random"))
+    cases["single_cloud_type_maxrand"] = (common(dict(base)), dict(cloud_optical_properties="single_cloud_type", cloud_overlap_method="maximum_random"))
+    cases["liquid_ice_fu_maximum"] = (common(dict(base)), dict(cloud_ice_properties="fu", cloud_overlap_method="maximum"))
+    cases["mcica_kissvec_maxrand_streamer"] = (common(dict(base)), dict(mcica=True, random_number_generator="kissvec", cloud_overlap_method="maximum_random",
+                                                                       cloud_ice_properties="key_streamer_manual"))
+    cases["mcica_twister_direct_input"] = (common(dict(base)), dict(mcica=True, cloud_optical_properties="direct_input"))
+    # external interface temperatures + every array handed over with its axes in ANOTHER order (lon, lat, levels[, bands])
+    st = common(dict(base))
+    tint = np.concatenate([st["surface_temperature"][0][None], 0.5 * (st["air_temperature"][0][1:] + st["air_temperature"][0][:-1]) + rng.uniform(-1, 1, (L - 1, ny, nx)),
+                           st["air_temperature"][0][-1:]], axis=0)
+    st["air_temperature_on_interface_levels"] = (tint, ("interface_levels", "lat", "lon"), "degK")
+    for k, (v, dims, units) in list(st.items()):
+        if "lat" in dims and "lon" in dims:
+            new = tuple(sorted(dims, key=lambda d: {"lon": 0, "lat": 1}.get(d, 2 + dims.index(d))))
+            st[k] = (np.ascontiguousarray(np.transpose(v, [dims.index(d) for d in new])), new, units)
+    cases["external_tint_axes_reordered"] = (st, dict(calculate_interface_temperature=False, cloud_overlap_method="random"))
+    return cases
+
+
+def reference_lw_class_cases():
+    """ref_lwclass_<name>.npz: what climt.RRTMGLongwave(**kwargs)(state) returns when its Fortran runs on this build's
+    (synthetic) longwave tables -- (i) the four states of the reference's own longwave cache classes
+    (tests/test_components.py:435-480), (ii) the perturbed states above, stored in the file."""
+    import json
+    from oracle.ref_driver import RefLW
+    from tools.pack_tables import read_blob
+    from tools.synth_lw_tables import fill_reference_from_blob
+    blob = read_blob(os.path.join(ROOT, "climt_amd", "data", "rrtmg_lw_data.bin"))
+    lw = RefLW()
+    lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+    todo = {}
+    for cls, desc, kw in (("TestRRTMGLongwave", "column", {}),
+                          ("TestRRTMGLongwaveWithClouds", "column", dict(cloud_optical_properties="single_cloud_type")),
+                          ("TestRRTMGLongwaveWithExternalInterfaceTemperature", "column", dict(calculate_interface_temperature=False)),
+                          ("TestRRTMGLongwaveMCICA", "3d", dict(mcica=True))):
+        z = np.load(os.path.join(OUT, "climt_cache_%s-%s.npz" % (cls, desc)))
+        st = {k.split("/")[1]: (z[k], tuple(str(z[k[:-6] + "dims"]).split(",")), str(z[k[:-6] + "units"]))
+              for k in z.files if k.startswith("state/") and k.endswith("/values")}
+        todo["%s-%s" % (cls, desc)] = (st, kw, False)
+    for name, (st, kw) in _lw_class_perturbed_states().items():
+        todo[name] = (st, kw, True)
+    for name, (st, kw, store_state) in todo.items():
+        exp, c = lw_class_reference(st, kw, lw)
+        save = {"kwargs": np.array(json.dumps(kw)), "synthetic_tables": np.array(int(np.ravel(blob.get("lw/meta/synthetic", np.array([0])))[0]))}
+        if store_state:
+            for k, (v, d, u) in st.items():
+                save["state/%s/values" % k] = v
+                save["state/%s/dims" % k] = np.array(",".join(d))
+                save["state/%s/units" % k] = np.array(u)
+        for grp, dd in exp.items():
+            for k, (v, d, u) in dd.items():
+                assert np.all(np.isfinite(v)), (name, k)
+                save["%s/%s/values" % (grp, k)] = v
+                save["%s/%s/dims" % (grp, k)] = np.array(",".join(d))
+                save["%s/%s/units" % (grp, k)] = np.array(u)
+        np.savez_compressed(os.path.join(OUT, "ref_lwclass_%s.npz" % name), **save)
+        print("longwave class case", name, kw, "OLR", float(exp["diag"]["upwelling_longwave_flux_in_air"][0][-1].mean()),
+              "cloud effect", float(np.abs(exp["diag"]["upwelling_longwave_flux_in_air"][0] - exp["diag"]["upwelling_longwave_flux_in_air_assuming_clear_sky"][0]).max()))
+
+
 if __name__ == "__main__":
+    if sys.argv[1:] == ["lwclass"]:
+        reference_lw_class_cases()
+        sys.exit(0)
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
                 "TestRRTMGLongwaveWithExternalInterfaceTemperature", "TestRRTMGShortwave", "TestRRTMGShortwaveMCICA"):
@@ -365,3 +564,4 @@ if __name__ == "__main__":
     reference_option_cases()
     for cls in ("TestRRTMGShortwave", "TestRRTMGLongwave"):
         cache_outputs_only(cls, "3d")
+    reference_lw_class_cases()

@@ -198,6 +198,60 @@ def maxdiff(a, b):
     return float(np.max(np.abs(np.asarray(a) - np.asarray(b))))
 
 
+# ---- the longwave drop-in class against the reference Fortran fed by an independent restatement of the reference's host layer
+# (tests/golden/make_golden.py::reference_lw_class_cases; on this build's table blob -- synthetic while the data file is missing)
+LW_CACHE_CLASSES = (("TestRRTMGLongwave", "column", {}),
+                    ("TestRRTMGLongwaveWithClouds", "column", dict(cloud_optical_properties="single_cloud_type")),
+                    ("TestRRTMGLongwaveWithExternalInterfaceTemperature", "column", dict(calculate_interface_temperature=False)),
+                    ("TestRRTMGLongwaveMCICA", "3d", dict(mcica=True)))
+LWCLASS_CASES = tuple(sorted(f[len("ref_lwclass_"):-len(".npz")] for f in os.listdir(GOLDEN) if f.startswith("ref_lwclass_") and f.endswith(".npz")))
+
+
+def load_lwclass_case(name):
+    """-> (state of DataArrays, constructor kwargs, expected tendencies, expected diagnostics, fixture made on synthetic tables?).
+    The four cases named after the reference's cache classes take their state from the cache fixture."""
+    import json
+    from climt_amd._sympl_compat import DataArray
+    z = np.load(os.path.join(GOLDEN, "ref_lwclass_%s.npz" % name))
+    groups = {"state": {}, "tend": {}, "diag": {}}
+    for k in z.files:
+        if "/" in k:
+            grp, q, what = k.split("/")
+            groups[grp].setdefault(q, {})[what] = z[k]
+    def mk(d):
+        return DataArray(d["values"], dims=tuple(x for x in str(d["dims"]).split(",") if x), attrs={"units": str(d["units"])})
+    if groups["state"]:
+        state = {n: mk(d) for n, d in groups["state"].items()}
+        state["time"] = datetime.datetime(2000, 1, 1)
+    else:
+        state = load_cache_case(*name.rsplit("-", 1))[0]
+    return (state, json.loads(str(z["kwargs"])), {n: mk(d) for n, d in groups["tend"].items()}, {n: mk(d) for n, d in groups["diag"].items()},
+            bool(int(z["synthetic_tables"])))
+
+
+def check_lwclass_case(name, make_component, tol=1e-9):
+    """Run climt_amd.RRTMGLongwave(**kwargs)(state) (make_component(**kwargs) builds it) and compare every returned quantity."""
+    state, kw, tend, diag, synthetic = load_lwclass_case(name)
+    comp = make_component(**kw)
+    assert comp._ctx.lw_tables_synthetic() == synthetic, "ref_lwclass_* fixtures were made on another table blob: python tests/golden/make_golden.py lwclass"
+    np.random.seed(0)                                     # tests/test_components.py:148
+    t, d = comp(state)
+    assert set(t) == set(tend) and set(d) == set(diag)
+    worst = 0.0
+    for got, exp in ((t, tend), (d, diag)):
+        for k in exp:
+            assert got[k].attrs["units"].replace("degK", "K") == exp[k].attrs["units"].replace("degK", "K")
+            assert set(got[k].dims) == set(exp[k].dims), (k, got[k].dims, exp[k].dims)
+            g = np.transpose(got[k].values, [got[k].dims.index(x) for x in exp[k].dims])
+            assert g.shape == exp[k].values.shape
+            dd = maxdiff(g, exp[k].values)
+            assert dd <= tol, (name, k, dd)
+            worst = max(worst, dd)
+    assert d["air_temperature_tendency_from_longwave"].values is t["air_temperature"].values or \
+        np.array_equal(d["air_temperature_tendency_from_longwave"].values, t["air_temperature"].values)
+    return worst
+
+
 LWMR_CASES = ("maxrand", "maxrand_idrv", "maximum")
 
 

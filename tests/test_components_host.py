@@ -12,7 +12,7 @@ import climt_amd
 from climt_amd import _sympl_compat as sc
 from climt_amd._util import get_interface_values, mass_to_volume_mixing_ratio
 from climt_amd.rrtmg import common, longwave, shortwave
-from helpers import GOLDEN, ROOT, EmuContext, load_cache_case, maxdiff
+from helpers import GOLDEN, LW_CACHE_CLASSES, LWCLASS_CASES, ROOT, EmuContext, check_lwclass_case, load_cache_case, maxdiff
 
 
 @pytest.fixture(autouse=True)
@@ -69,22 +69,46 @@ def test_shortwave_mcica_reproduces_reference_cache():
     _check_against_cache(climt_amd.RRTMGShortwave(mcica=True), "TestRRTMGShortwaveMCICA", "column", 1e-8)
 
 
-@pytest.mark.parametrize("cls,desc,kw", [
-    ("TestRRTMGLongwave", "column", {}),
-    ("TestRRTMGLongwaveWithClouds", "column", dict(cloud_optical_properties="single_cloud_type")),
-    ("TestRRTMGLongwaveWithExternalInterfaceTemperature", "column", dict(calculate_interface_temperature=False)),
-    ("TestRRTMGLongwaveMCICA", "3d", dict(mcica=True)),
-])
+@pytest.mark.parametrize("cls,desc,kw", LW_CACHE_CLASSES)
 def test_longwave_on_reference_states(cls, desc, kw):
-    """The reference's four longwave cache classes (tests/test_components.py:435-480).  With the SYNTHETIC k-tables of
-    this build the numbers cannot match (LW parity is pinned against the reference Fortran on the same tables instead):
-    names, dims, units and finiteness are checked.  The day the real table file is packed the comparison switches itself
-    on at the reference's own criterion, 1e-8."""
+    """The reference's four longwave cache classes (tests/test_components.py:435-480).  While the table blob is SYNTHETIC
+    the cached numbers cannot match; the VALUES the class returns on these four states are then pinned to the reference
+    Fortran on the same tables (ref_lwclass_<class>-<desc>.npz: the reference's host layer restated independently in
+    tests/golden/make_golden.py) at 1e-9.  The day the real table file is packed the comparison against the caches switches
+    itself on at the reference's own criterion, 1e-8."""
     comp = climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **kw)
-    tol = None if comp._ctx.lw_tables_synthetic() else 1e-8
-    t, d = _check_against_cache(comp, cls, desc, tol)
-    assert d["air_temperature_tendency_from_longwave"].values is not None
+    if comp._ctx.lw_tables_synthetic():
+        t, d = _check_against_cache(comp, cls, desc, None)
+        assert check_lwclass_case("%s-%s" % (cls, desc), lambda **k: climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **k)) <= 1e-9
+    else:
+        t, d = _check_against_cache(comp, cls, desc, 1e-8)
     assert np.array_equal(d["air_temperature_tendency_from_longwave"].values, t["air_temperature"].values)
+
+
+@pytest.mark.parametrize("name", [n for n in LWCLASS_CASES if not n.startswith("TestRRTMG")])
+def test_longwave_class_values_on_perturbed_states(name):
+    """Every optional input of the class non-trivial along every axis (band-dependent emissivity, aerosol and cloud optical
+    depths, clouds of both phases, trace gases, humidity), each cloud option / overlap / generator once, one state handed over
+    with its axes in another order and external interface temperatures: a transposed axis, a missing unit factor or a wrong
+    flag changes these numbers by W m-2, the bar is 1e-9."""
+    check_lwclass_case(name, lambda **k: climt_amd.RRTMGLongwave(allow_synthetic_tables=True, **k))
+
+
+def test_change_up_flux_arrays_are_not_overwritten_by_the_next_call():
+    """calculate_change_up_flux=True publishes dF/dTs on the instance; an array a caller kept from call N holds call N's
+    numbers after call N+1 (they come from the liveness-tracked output pool like every other result)."""
+    lw = climt_amd.RRTMGLongwave(allow_synthetic_tables=True, calculate_change_up_flux=True)
+    state, _, _ = load_cache_case("TestRRTMGLongwave", "column")
+    lw(state)
+    kept = lw.change_in_upward_flux_with_surface_temperature
+    snapshot = kept.copy()
+    assert np.all(snapshot > 0.0)
+    ts = state["surface_temperature"]
+    state["surface_temperature"] = type(ts)(ts.values + 15.0, dims=ts.dims, attrs=ts.attrs)
+    lw(state)
+    assert lw.change_in_upward_flux_with_surface_temperature is not kept
+    assert np.array_equal(kept, snapshot)
+    assert maxdiff(lw.change_in_upward_flux_with_surface_temperature, snapshot) > 0.0
 
 
 def test_state_axis_permutation_invariance():
