@@ -285,37 +285,45 @@ def load_opt_case(name):
 # ---- the live oracle on many columns: reference library (oracle/_ref) if it travelled, else the C restatement ----------
 def _live_oracle_worker(args):
     """One host process (the reference Fortran keeps process-global state): SW and LW of one column chunk."""
-    chunk, mcica = args
+    chunk, mcica, spectra = args
     sys.path.insert(0, ROOT)
     from oracle import ref_driver
+    sw = lw = None
     if ref_driver.available("sw") and ref_driver.available("lw"):
         from tools.pack_tables import read_blob
         from tools.synth_lw_tables import fill_reference_from_blob
-        rsw = ref_driver.RefSW()
-        blob = read_blob(LW_DATA)
-        rlw = ref_driver.RefLW(); rlw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
-        sw, lw = rsw.fluxes(chunk, mcica=mcica), rlw.fluxes(chunk, mcica=mcica)
+        if "sw" in spectra:
+            sw = ref_driver.RefSW().fluxes(chunk, mcica=mcica)
+        if "lw" in spectra:
+            blob = read_blob(LW_DATA)
+            rlw = ref_driver.RefLW(); rlw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
+            lw = rlw.fluxes(chunk, mcica=mcica)
         kind = "reference"
     else:
         from oracle.port_driver import PortLW, PortSW
-        sw, lw = PortSW().fluxes(chunk, mcica=mcica), PortLW().fluxes(chunk, mcica=mcica)
+        if "sw" in spectra:
+            sw = PortSW().fluxes(chunk, mcica=mcica)
+        if "lw" in spectra:
+            lw = PortLW().fluxes(chunk, mcica=mcica)
         kind = "port"
-    return ({k: sw[k] for k, _ in SW_OUT}, {k: lw[k] for k, _ in LW_OUT}, kind)
+    return ({k: sw[k] for k, _ in SW_OUT} if sw else None, {k: lw[k] for k, _ in LW_OUT} if lw else None, kind)
 
 
-def live_oracle(c, mcica, chunk=128, procs=None):
+def live_oracle(c, mcica, chunk=128, procs=None, spectra=("sw", "lw"), timeout=900):
     """SW and LW outputs of the oracle for the columns of `c` (kissvec or clear sky: columns are independent), computed in
-    column chunks on a pool of host processes -> (sw dict, lw dict, 'reference' | 'port')."""
+    column chunks on a pool of host processes -> (sw dict, lw dict, 'reference' | 'port'); a spectrum not asked for is None.
+    (The reference Fortran `stop`s on inputs it refuses -- fractional clouds in the non-McICA shortwave, say -- which ends
+    the worker process and would leave Pool.map waiting for ever: the wait is bounded.)"""
     import multiprocessing as mp
     from climt_amd.distributed import slice_columns
     ncol = c["play"].shape[1]
     c = {k: v for k, v in c.items() if k != "lat"}
-    jobs = [(slice_columns(c, s, min(ncol, s + chunk)), mcica) for s in range(0, ncol, chunk)]
+    jobs = [(slice_columns(c, s, min(ncol, s + chunk)), mcica, tuple(spectra)) for s in range(0, ncol, chunk)]
     procs = procs or max(1, min(len(jobs), os.cpu_count() or 1, 32))
     with mp.get_context("spawn").Pool(procs) as pool:
-        parts = pool.map(_live_oracle_worker, jobs)
-    sw = {k: np.concatenate([p[0][k] for p in parts], axis=1) for k, _ in SW_OUT}
-    lw = {k: np.concatenate([p[1][k] for p in parts], axis=1) for k, _ in LW_OUT}
+        parts = pool.map_async(_live_oracle_worker, jobs).get(timeout=timeout)
+    sw = {k: np.concatenate([p[0][k] for p in parts], axis=1) for k, _ in SW_OUT} if "sw" in spectra else None
+    lw = {k: np.concatenate([p[1][k] for p in parts], axis=1) for k, _ in LW_OUT} if "lw" in spectra else None
     require_reference_oracle(parts[0][2])
     assert all(p[2] == parts[0][2] for p in parts)
     return sw, lw, parts[0][2]
