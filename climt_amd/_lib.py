@@ -25,13 +25,18 @@ class RRTMGError(RuntimeError):
         self.code = code
 
 
+# unit factors the library applies to host arrays on the device (include/rrtmg_hip.h: rrtmg_sw_args, last four fields)
+_SCALES = ("pressure_scale", "water_path_scale", "h2o_mul", "h2o_div")
+
+
 class SwArgs(C.Structure):
     _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld iaer inflgsw iceflgsw liqflgsw dyofyr isolvar "
                                      "irng permuteseed shard_col0 shard_ncol reserved0").split()]
                 + [(n, _f64) for n in "adjes scon solcycfrac".split()]
                 + [(n, _vp) for n in ("bndsolvar indsolvar play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr "
                                       "asdir asdif aldir aldif coszen cldfr taucld ssacld asmcld fsfcld cicewp cliqwp reice "
-                                      "reliq tauaer ssaaer asmaer ecaer cldfmcl swuflx swdflx swhr swuflxc swdflxc swhrc").split()])
+                                      "reliq tauaer ssaaer asmaer ecaer cldfmcl swuflx swdflx swhr swuflxc swdflxc swhrc").split()]
+                + [(n, _f64) for n in _SCALES])
 
 
 class LwArgs(C.Structure):
@@ -39,7 +44,8 @@ class LwArgs(C.Structure):
                                      "shard_col0 shard_ncol reserved0").split()]
                 + [(n, _vp) for n in ("play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr cfc11vmr cfc12vmr "
                                       "cfc22vmr ccl4vmr emis cldfr taucld cicewp cliqwp reice reliq tauaer cldfmcl "
-                                      "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()])
+                                      "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()]
+                + [(n, _f64) for n in _SCALES])
 
 
 SLAB_IN = ("sw_down lw_down sw_up lw_up lh sh up_heat_soil heat_flux_sea_ice sea_water_dens surf_dens heat_cap_soil surf_therm_cap "
@@ -309,6 +315,9 @@ class Context:
         for k, f in flags.items():
             if k in inp:
                 setattr(a, f, int(inp[k]))
+        for k in _SCALES:
+            if inp.get(k):
+                setattr(a, k, float(inp[k]))
         for k, f in fields.items():
             v = inp.get(k)
             if v is None:

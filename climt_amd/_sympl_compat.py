@@ -175,11 +175,17 @@ except ImportError:
             if plan is None:
                 plan = plans[sig] = self._plan(state)
             steps, self._dim_lengths, self._wild_names, self._wild_shape = plan
+            # components whose library applies unit factors on the device name the inputs it may do that for
+            # (climt_amd/rrtmg: pressures, cloud water paths): those go through unconverted, the factor beside them
+            on_device = getattr(self, "_unit_factor_on_device", ())
+            raw["_unit_factors"] = unit_factors = {}
             for name, numeric, factor, order, shape in steps:
                 values = np.asarray(state[name].values)
                 if numeric:
                     values = values.astype(np.float64, copy=False)
-                    if factor is not None:
+                    if factor is not None and name in on_device and values.ndim >= 2:
+                        unit_factors[name] = factor
+                    elif factor is not None:
                         if staging is not None and values.ndim >= 2:
                             values = staging.scaled(name, values, factor)
                             if order is not None:

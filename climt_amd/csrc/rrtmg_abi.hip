@@ -5,6 +5,8 @@
 #include <mutex>
 
 #include <atomic>
+#include <condition_variable>
+#include <memory>
 
 #include "rrtmg_ctx.h"
 
@@ -99,32 +101,139 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
   return RRTMG_OK;
 }
 
-// true when every one of the n doubles at p is +0.0 (all bits clear).  The head is checked first (an array with data in it
-// is recognised in microseconds); an array that passes that is scanned in slices on a few host threads, each giving up as
-// soon as any of them has found a set bit.
-bool host_all_zero(const double *p, size_t n) {
-  const uint64_t *q = (const uint64_t *)p;
-  const size_t head = n < 4096 ? n : 4096;
-  for (size_t i = 0; i < head; ++i) if (q[i]) return false;
-  if (n == head) return true;
-  unsigned nt = std::thread::hardware_concurrency();
-  nt = nt == 0 ? 1 : (nt > 8 ? 8 : nt);
-  if (n < ((size_t)1 << 19)) nt = 1;
-  std::atomic<bool> found(false);
-  auto work = [&](unsigned t) {
-    const size_t per = (n + nt - 1) / nt, lo = (size_t)t * per, hi = lo + per < n ? lo + per : n;
-    for (size_t i = lo; i < hi && !found.load(std::memory_order_relaxed); i += 4096) {
+// ---- host-pointer inputs (rrtmg_host_inputs.h) ---------------------------------------------------------------------------
+namespace {
+// A few persistent host threads that scan input arrays (created on first use, never joined: they sleep between calls and
+// end with the process).  The caller of wait() works the queue too, so a batch completes even in a process that has no
+// workers (a fork()ed child of a process that had started them).
+struct ScanJob {
+  const uint64_t *q = nullptr;
+  size_t n = 0;
+  uint64_t first = 0;
+  std::atomic<bool> differs{false};
+};
+constexpr size_t kSliceWords = (size_t)1 << 16;   // 512 KB per task
+class HostPool {
+ public:
+  struct Batch { std::atomic<long> open{0}; };
+  static HostPool &get() { static HostPool *pool = new HostPool(); return *pool; }
+  void start(ScanJob *jobs, int njobs, Batch &b) {
+    std::lock_guard<std::mutex> lk(m_);
+    for (int j = 0; j < njobs; ++j)
+      for (size_t lo = 0; lo < jobs[j].n; lo += kSliceWords) { tasks_.push_back(Task{&jobs[j], lo, &b}); b.open.fetch_add(1, std::memory_order_relaxed); }
+    cv_.notify_all();
+  }
+  void wait(Batch &b) {
+    for (;;) {   // help: take tasks (of any batch) until the queue is empty ...
+      Task t;
+      { std::lock_guard<std::mutex> lk(m_); if (tasks_.empty()) break; t = tasks_.back(); tasks_.pop_back(); }
+      run(t);
+    }
+    while (b.open.load(std::memory_order_acquire) > 0) std::this_thread::yield();   // ... then for the slices workers still hold
+  }
+
+ private:
+  struct Task { ScanJob *job; size_t lo; Batch *batch; };
+  HostPool() {
+    unsigned n = std::thread::hardware_concurrency();
+    n = n <= 2 ? 1 : (n / 2 > 16 ? 16 : n / 2);
+    if (const char *env = getenv("RRTMG_HIP_HOST_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 64) n = (unsigned)v; }
+    for (unsigned i = 0; i < n; ++i) std::thread([this] { loop(); }).detach();
+  }
+  void loop() {
+    for (;;) {
+      Task t;
+      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return !tasks_.empty(); }); t = tasks_.back(); tasks_.pop_back(); }
+      run(t);
+    }
+  }
+  static void run(const Task &t) {
+    ScanJob &j = *t.job;
+    const size_t hi = t.lo + kSliceWords < j.n ? t.lo + kSliceWords : j.n;
+    for (size_t i = t.lo; i < hi && !j.differs.load(std::memory_order_relaxed); i += 4096) {
       const size_t e = i + 4096 < hi ? i + 4096 : hi;
       uint64_t acc = 0;
-      for (size_t j = i; j < e; ++j) acc |= q[j];
-      if (acc) found.store(true, std::memory_order_relaxed);
+      for (size_t k = i; k < e; ++k) acc |= j.q[k] ^ j.first;
+      if (acc) j.differs.store(true, std::memory_order_relaxed);
     }
-  };
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
-  work(0);
-  for (auto &x : th) x.join();
-  return !found.load();
+    t.batch->open.fetch_sub(1, std::memory_order_release);
+  }
+  std::mutex m_;
+  std::condition_variable cv_;
+  std::vector<Task> tasks_;
+};
+}  // namespace
+
+void HostInputs::add(const double **slot, const double *host, size_t n, const char *name, bool required, InPolicy policy, double mul, double div) {
+  *slot = nullptr;
+  if (!host) {
+    if (required) { ctx_->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok_ = false; }
+    return;
+  }
+  if (memspace_ == 1) { *slot = host; return; }   // device pointers are used as they are
+  Entry e{slot, host, n, name, policy, mul, div};
+  entries_.push_back(e);
+}
+
+bool HostInputs::upload(const Entry &e) {
+  const std::string key = std::string(prefix_) + e.name;
+  double *dp = (double *)ctx_->buf(key, e.n * sizeof(double));
+  if (!dp) return false;
+  ctx_->bufs[key].uniform = false;
+  if (hipMemcpyAsync(dp, e.host, e.n * sizeof(double), hipMemcpyHostToDevice, s_) != hipSuccess) { ctx_->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", e.name); return false; }
+  if (e.mul != 0.0) launch_scale(s_, dp, e.n, e.mul, e.div);
+  *e.slot = dp;
+  return true;
+}
+
+bool HostInputs::fill(const Entry &e, double host_value) {
+  // the value numpy would have formed on the host: one rounding per operation
+  volatile double v = host_value;
+  if (e.mul != 0.0) { v = v * e.mul; if (e.div != 0.0) v = v / e.div; }
+  const double value = v;
+  const std::string key = std::string(prefix_) + e.name;
+  double *dp = (double *)ctx_->buf(key, e.n * sizeof(double));
+  if (!dp) return false;
+  DevBuf &b = ctx_->bufs[key];
+  if (!(b.uniform && b.uni_n == e.n && memcmp(&b.uni_value, &value, sizeof value) == 0)) {
+    launch_fill(s_, dp, e.n, value);
+    b.uniform = true; b.uni_value = value; b.uni_n = e.n;
+  }
+  *e.slot = dp;
+  return true;
+}
+
+bool HostInputs::finish() {
+  if (!ok_) return false;
+  std::unique_ptr<ScanJob[]> jobs(new ScanJob[entries_.size() + 1]);
+  int njobs = 0;
+  for (Entry &e : entries_) {
+    if (e.n < kScanMin) continue;
+    const uint64_t *q = (const uint64_t *)e.host;
+    const uint64_t w0 = q[0];
+    uint64_t acc = 0;
+    for (size_t i = 1; i < 2048; ++i) acc |= q[i] ^ w0;                       // the head ...
+    for (size_t k = 1; k <= 16; ++k) acc |= q[(e.n - 1) / 16 * k] ^ w0;        // ... and sixteen places further on
+    if (acc) continue;                                                         // certainly not uniform: goes up at once
+    e.job = njobs;
+    jobs[njobs].q = q; jobs[njobs].n = e.n; jobs[njobs].first = w0;
+    ++njobs;
+  }
+  HostPool::Batch batch;
+  if (njobs) HostPool::get().start(jobs.get(), njobs, batch);
+  for (const Entry &e : entries_)
+    if (e.job < 0 && !upload(e)) ok_ = false;
+  if (njobs) HostPool::get().wait(batch);
+  for (const Entry &e : entries_) {
+    if (e.job < 0) continue;
+    const ScanJob &j = jobs[e.job];
+    if (j.differs.load()) { if (!upload(e)) ok_ = false; continue; }
+    if (e.policy == InPolicy::ZeroAbsent && j.first == 0) { *e.slot = nullptr; continue; }   // all +0.0: the "array absent" path adds the same
+    double v;
+    memcpy(&v, &j.first, sizeof v);
+    if (!fill(e, v)) ok_ = false;
+  }
+  return ok_;
 }
 
 std::string default_blob_path(const char *which) {

@@ -12,6 +12,7 @@
 
 #include "../../include/rrtmg_hip.h"
 #include "rrtmg_common.h"
+#include "rrtmg_host_inputs.h"
 #include "rrtmg_tables.h"
 
 namespace rrtmg {
@@ -19,6 +20,11 @@ namespace rrtmg {
 struct DevBuf {
   void *p = nullptr;
   size_t cap = 0;
+  // an INPUT buffer that was last filled with one value (rrtmg_host_inputs.h): the next call that finds the same uniform array
+  // on the host has nothing to do.  Cleared by every upload into the buffer and when it is re-allocated.
+  bool uniform = false;
+  double uni_value = 0.0;
+  size_t uni_n = 0;
 };
 
 }  // namespace rrtmg
@@ -109,6 +115,7 @@ struct rrtmg_ctx {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+    b.uniform = false;
     size_t want = bytes < 256 ? 256 : bytes;
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) {
@@ -130,13 +137,6 @@ namespace rrtmg {
 void launch_interface_values(hipStream_t s, int ncol, int nlay, const double *mid, const double *surf, const double *pmid, const double *pint, double *out);
 struct OutCopy { double *host; const double *dev; size_t n; };
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host);
-// Host arrays that only ADD something to the problem when they hold a non-zero -- band optical depths of clouds given directly
-// and of aerosols: 14 / 16 values per layer and column, 55-63 MB each at 8192 x 60, half of what a drop-in call would send over
-// PCIe, and all zeros unless the model has such clouds / aerosols -- are scanned on the host (memory rate, in the background
-// while the other inputs are uploaded) and not uploaded when they are entirely +0.0: the device code then takes its "array
-// absent" path, which adds the same +0.0.  (Only for arrays of tens of MB: a 4 MB array is uploaded sooner than scanned.)
-bool host_all_zero(const double *p, size_t n);
-constexpr size_t kZeroScanMin = (size_t)1 << 20;   // doubles (8 MB): below this an array is simply uploaded
 }  // namespace rrtmg
 
 #define RRTMG_HIP_CHECK(ctx, call)                                                                     \

@@ -210,42 +210,30 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const bool maxrand = !d.mcica && d.icld >= 2;   // rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544)
   if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
 
+  // ---- inputs (rrtmg_host_inputs.h: uniform arrays are filled on the device, all-zero band arrays are absent) ----------------
   bool ok = true;
-  auto in = [&](const double *p, size_t n, const char *name, bool required, std::future<bool> *all_zero = nullptr) -> const double * {
-    if (!p) {
-      if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
-      return nullptr;
-    }
-    if (a->memspace == 1) return p;
-    if (all_zero && all_zero->valid() && all_zero->get()) return nullptr;   // (rrtmg_ctx.h, host_all_zero: nothing to add, nothing to send)
-    double *dp = (double *)ctx->buf(std::string("lw.in.") + name, n * sizeof(double));
-    if (!dp) { ok = false; return nullptr; }
-    if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
-    return dp;
-  };
-  // the band arrays that may turn out to be all zeros are scanned in the background while the other inputs go up
-  std::future<bool> z_tauaer, z_taucld;
-  if (a->memspace == 0 && nl * 16 >= kZeroScanMin) {
-    if (a->tauaer) z_tauaer = std::async(std::launch::async, host_all_zero, a->tauaer, nl * 16);
-    if (a->taucld && d.icld >= 1 && d.inflag != 0) z_taucld = std::async(std::launch::async, host_all_zero, a->taucld, nl * 16);
-  }
-  d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
-  d.tlev = in(a->tlev, nl1, "tlev", false); d.tsfc = in(a->tsfc, N, "tsfc", true);
-  d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
-  d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
-  d.cfc11 = in(a->cfc11vmr, nl, "cfc11", false); d.cfc12 = in(a->cfc12vmr, nl, "cfc12", false);
-  d.cfc22 = in(a->cfc22vmr, nl, "cfc22", false); d.ccl4 = in(a->ccl4vmr, nl, "ccl4", false);
-  d.emis = in(a->emis, (size_t)N * 16, "emis", true);
+  const double ps = a->pressure_scale, ws = a->water_path_scale;
+  HostInputs hi(ctx, s, "lw.in.", a->memspace);
+  hi.add(&d.play, a->play, nl, "play", true, InPolicy::Plain, ps); hi.add(&d.plev, a->plev, nl1, "plev", true, InPolicy::Plain, ps);
+  hi.add(&d.tlay, a->tlay, nl, "tlay", true); hi.add(&d.tlev, a->tlev, nl1, "tlev", false); hi.add(&d.tsfc, a->tsfc, N, "tsfc", true);
+  hi.add(&d.h2o, a->h2ovmr, nl, "h2o", true, InPolicy::Plain, a->h2o_mul, a->h2o_div); hi.add(&d.o3, a->o3vmr, nl, "o3", true);
+  hi.add(&d.co2, a->co2vmr, nl, "co2", true); hi.add(&d.ch4, a->ch4vmr, nl, "ch4", true); hi.add(&d.n2o, a->n2ovmr, nl, "n2o", true);
+  hi.add(&d.o2, a->o2vmr, nl, "o2", true);
+  hi.add(&d.cfc11, a->cfc11vmr, nl, "cfc11", false); hi.add(&d.cfc12, a->cfc12vmr, nl, "cfc12", false);
+  hi.add(&d.cfc22, a->cfc22vmr, nl, "cfc22", false); hi.add(&d.ccl4, a->ccl4vmr, nl, "ccl4", false);
+  hi.add(&d.emis, a->emis, (size_t)N * 16, "emis", true);
   const bool clouds = d.icld >= 1;
   if (clouds) {
-    d.cldfr = in(a->cldfr, nl, "cldfr", true);
-    d.taucld = in(a->taucld, nl * 16, "taucld", d.inflag == 0, &z_taucld);
-    d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag >= 1); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag >= 1);
-    d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
+    hi.add(&d.cldfr, a->cldfr, nl, "cldfr", true);
+    // (given directly -- inflag 0 -- the cloud optical depth is used as it is; otherwise zeros mean there is none to add)
+    hi.add(&d.taucld, a->taucld, nl * 16, "taucld", d.inflag == 0, d.inflag == 0 ? InPolicy::Plain : InPolicy::ZeroAbsent);
+    hi.add(&d.cicewp, a->cicewp, nl, "cicewp", d.inflag >= 1, InPolicy::Plain, ws); hi.add(&d.cliqwp, a->cliqwp, nl, "cliqwp", d.inflag >= 1, InPolicy::Plain, ws);
+    hi.add(&d.reice, a->reice, nl, "reice", d.inflag == 2); hi.add(&d.reliq, a->reliq, nl, "reliq", d.inflag == 2);
   }
-  d.tauaer = in(a->tauaer, nl * 16, "tauaer", false, &z_tauaer);
-  if (z_taucld.valid()) (void)z_taucld.get();
-  if (!ok) return ctx->status;
+  hi.add(&d.tauaer, a->tauaer, nl * 16, "tauaer", false, InPolicy::ZeroAbsent);
+  const double *cldfmcl_dev = nullptr;
+  if (clouds && d.mcica && a->cldfmcl) hi.add(&cldfmcl_dev, a->cldfmcl, nl * kLwNGpt, "cldfmcl", true);
+  if (!hi.finish()) return ctx->status;
 
   auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("lw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
   d.prep = wd("prep", lw_prep_size(N, L));
@@ -311,9 +299,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   if (clouds) {
     if (d.mcica) {
       if (a->cldfmcl) {
-        const double *cm = in(a->cldfmcl, nl * kLwNGpt, "cldfmcl", true);
-        if (!ok) return ctx->status;
-        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kLwNGpt), blk, 0, s, N, L, kLwNGpt, cm, d.mask, d.nw);
+        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kLwNGpt), blk, 0, s, N, L, kLwNGpt, cldfmcl_dev, d.mask, d.nw);
       } else if (a->irng == 0) {
         const uint32_t *jumps = kiss_jumps_device(ctx, 1, kLwNGpt, L, d.icld, a->permuteseed, s);
         if (!jumps) return ctx->status;

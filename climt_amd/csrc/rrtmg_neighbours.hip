@@ -253,6 +253,26 @@ __global__ void __launch_bounds__(256) copy_blocks_kernel(const int64_t *desc, c
   if (r >= q[2] || c >= q[3]) return;
   __builtin_nontemporal_store(__builtin_nontemporal_load(src + q[0] + r * q[4] + c), dst + q[1] + r * q[5] + c);
 }
+// inputs of host-pointer calls that did not have to cross PCIe (rrtmg_host_inputs.h): a fill, and the unit factor the caller
+// would have applied on the host (one rounding per operation, as numpy: contraction off)
+__global__ void __launch_bounds__(256) fill_kernel(double *p, size_t n, double value) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = value;
+}
+__global__ void __launch_bounds__(256) scale_kernel(double *p, size_t n, double mul, double div) {
+#pragma clang fp contract(off)
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double x = p[i] * mul;
+  if (div != 0.0) x = x / div;
+  p[i] = x;
+}
+void launch_fill(hipStream_t s, double *p, size_t n, double value) {
+  hipLaunchKernelGGL(fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, value);
+}
+void launch_scale(hipStream_t s, double *p, size_t n, double mul, double div) {
+  hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, mul, div);
+}
 void launch_interface_values(hipStream_t s, int ncol, int nlay, const double *mid, const double *surf, const double *pmid, const double *pint, double *out) {
   hipLaunchKernelGGL(interface_values_kernel, dim3((ncol + 255) / 256, nlay + 1), dim3(256), 0, s, ncol, nlay, mid, surf, pmid, pint, out);
 }

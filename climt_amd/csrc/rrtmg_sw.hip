@@ -297,52 +297,44 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (rc) return ctx->fail(rc, "%s", err.c_str());
   if (d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "inflgsw=1 has no shortwave implementation in RRTMG_SW (cldprop_sw handles 0 and 2)");
 
-  // ---- inputs -----------------------------------------------------------------------------
+  // ---- inputs (rrtmg_host_inputs.h: uniform arrays are filled on the device, all-zero band arrays are absent) ----------------
   bool ok = true;
-  auto in = [&](const double *p, size_t n, const char *name, bool required, std::future<bool> *all_zero = nullptr) -> const double * {
-    if (!p) {
-      if (required) { ctx->fail(RRTMG_ERR_ARG, "required array '%s' is NULL", name); ok = false; }
-      return nullptr;
-    }
-    if (a->memspace == 1) return p;
-    if (all_zero && all_zero->valid() && all_zero->get()) return nullptr;   // (rrtmg_ctx.h, host_all_zero: nothing to add, nothing to send)
-    double *dp = (double *)ctx->buf(std::string("sw.in.") + name, n * sizeof(double));
-    if (!dp) { ok = false; return nullptr; }
-    if (hipMemcpyAsync(dp, p, n * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) { ctx->fail(RRTMG_ERR_HIP, "H2D copy of '%s' failed", name); ok = false; }
-    return dp;
-  };
-  // the band array that may turn out to be all zeros is scanned in the background while the other inputs go up
-  std::future<bool> z_taucld;
-  if (a->memspace == 0 && nl * kSwNBand >= kZeroScanMin && a->taucld && d.icld >= 1 && d.inflag != 0) z_taucld = std::async(std::launch::async, host_all_zero, a->taucld, nl * kSwNBand);
-  d.play = in(a->play, nl, "play", true); d.plev = in(a->plev, nl1, "plev", true); d.tlay = in(a->tlay, nl, "tlay", true);
-  d.h2o = in(a->h2ovmr, nl, "h2o", true); d.o3 = in(a->o3vmr, nl, "o3", true); d.co2 = in(a->co2vmr, nl, "co2", true);
-  d.ch4 = in(a->ch4vmr, nl, "ch4", true); d.n2o = in(a->n2ovmr, nl, "n2o", true); d.o2 = in(a->o2vmr, nl, "o2", true);
-  d.asdir = in(a->asdir, N, "asdir", true); d.asdif = in(a->asdif, N, "asdif", true);
-  d.aldir = in(a->aldir, N, "aldir", true); d.aldif = in(a->aldif, N, "aldif", true);
-  d.coszen = in(a->coszen, N, "coszen", true);
+  const double ps = a->pressure_scale, ws = a->water_path_scale;
+  HostInputs hi(ctx, s, "sw.in.", a->memspace);
+  hi.add(&d.play, a->play, nl, "play", true, InPolicy::Plain, ps); hi.add(&d.plev, a->plev, nl1, "plev", true, InPolicy::Plain, ps);
+  hi.add(&d.tlay, a->tlay, nl, "tlay", true);
+  hi.add(&d.h2o, a->h2ovmr, nl, "h2o", true, InPolicy::Plain, a->h2o_mul, a->h2o_div); hi.add(&d.o3, a->o3vmr, nl, "o3", true);
+  hi.add(&d.co2, a->co2vmr, nl, "co2", true); hi.add(&d.ch4, a->ch4vmr, nl, "ch4", true); hi.add(&d.n2o, a->n2ovmr, nl, "n2o", true);
+  hi.add(&d.o2, a->o2vmr, nl, "o2", true);
+  hi.add(&d.asdir, a->asdir, N, "asdir", true); hi.add(&d.asdif, a->asdif, N, "asdif", true);
+  hi.add(&d.aldir, a->aldir, N, "aldir", true); hi.add(&d.aldif, a->aldif, N, "aldif", true);
+  hi.add(&d.coszen, a->coszen, N, "coszen", true);
   const bool clouds = d.icld >= 1;
   if (clouds) {
-    d.cldfr = in(a->cldfr, nl, "cldfr", true);
+    hi.add(&d.cldfr, a->cldfr, nl, "cldfr", true);
     const bool optics = (d.inflag == 0);
-
     // single-scattering albedo / asymmetry / forward fraction are read only where the optics are given directly -- under
     // inflag 2 they would multiply an optical depth below cldmin = 1e-20 at most -- so host copies are not uploaded then
     const bool up = optics || a->memspace == 1;
-    d.ssacld = up ? in(a->ssacld, nl * kSwNBand, "ssacld", optics) : nullptr;
-    d.asmcld = up ? in(a->asmcld, nl * kSwNBand, "asmcld", optics) : nullptr;
-    d.fsfcld = up ? in(a->fsfcld, nl * kSwNBand, "fsfcld", optics) : nullptr;
-    d.cicewp = in(a->cicewp, nl, "cicewp", d.inflag == 2); d.cliqwp = in(a->cliqwp, nl, "cliqwp", d.inflag == 2);
-    d.reice = in(a->reice, nl, "reice", d.inflag == 2); d.reliq = in(a->reliq, nl, "reliq", d.inflag == 2);
-    d.taucld = in(a->taucld, nl * kSwNBand, "taucld", optics, &z_taucld);   // (stays live under inflag 2: the tauctot gate of cldprop_sw)
+    if (up) {
+      hi.add(&d.ssacld, a->ssacld, nl * kSwNBand, "ssacld", optics); hi.add(&d.asmcld, a->asmcld, nl * kSwNBand, "asmcld", optics);
+      hi.add(&d.fsfcld, a->fsfcld, nl * kSwNBand, "fsfcld", optics);
+    }
+    hi.add(&d.cicewp, a->cicewp, nl, "cicewp", d.inflag == 2, InPolicy::Plain, ws); hi.add(&d.cliqwp, a->cliqwp, nl, "cliqwp", d.inflag == 2, InPolicy::Plain, ws);
+    hi.add(&d.reice, a->reice, nl, "reice", d.inflag == 2); hi.add(&d.reliq, a->reliq, nl, "reliq", d.inflag == 2);
+    // (stays live under inflag 2: the tauctot gate of cldprop_sw; given directly -- inflag 0 -- it is used as it is)
+    hi.add(&d.taucld, a->taucld, nl * kSwNBand, "taucld", optics, optics ? InPolicy::Plain : InPolicy::ZeroAbsent);
   }
   const double *ecaer = nullptr;
   if (d.iaer == 10) {
-    d.tauaer = in(a->tauaer, nl * kSwNBand, "tauaer", true); d.ssaaer = in(a->ssaaer, nl * kSwNBand, "ssaaer", true);
-    d.asmaer = in(a->asmaer, nl * kSwNBand, "asmaer", true);
+    hi.add(&d.tauaer, a->tauaer, nl * kSwNBand, "tauaer", true); hi.add(&d.ssaaer, a->ssaaer, nl * kSwNBand, "ssaaer", true);
+    hi.add(&d.asmaer, a->asmaer, nl * kSwNBand, "asmaer", true);
   } else if (d.iaer == 6) {
-    ecaer = in(a->ecaer, nl * 6, "ecaer", true);
+    hi.add(&ecaer, a->ecaer, nl * 6, "ecaer", true);
   }
-  if (!ok) return ctx->status;
+  const double *cldfmcl_dev = nullptr;
+  if (clouds && d.mcica && a->cldfmcl) hi.add(&cldfmcl_dev, a->cldfmcl, nl * kSwNGpt, "cldfmcl", true);
+  if (!hi.finish()) return ctx->status;
 
   // ---- work buffers -------------------------------------------------------------------------
   auto wd = [&](const char *name, size_t n) -> double * { double *p = (double *)ctx->buf(std::string("sw.w.") + name, n * sizeof(double)); if (!p) ok = false; return p; };
@@ -397,9 +389,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   if (clouds) {
     if (d.mcica) {
       if (a->cldfmcl) {
-        const double *cm = in(a->cldfmcl, nl * kSwNGpt, "cldfmcl", true);
-        if (!ok) return ctx->status;
-        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, kSwNGpt, cm, d.mask, d.nw);
+        hipLaunchKernelGGL(mask_from_cldfmcl_kernel, dim3(ntile, kSwNGpt), blk, 0, s, N, L, kSwNGpt, cldfmcl_dev, d.mask, d.nw);
       } else if (a->irng == 0) {
         const uint32_t *jumps = kiss_jumps_device(ctx, 0, kSwNGpt, L, d.icld, a->permuteseed, s);
         if (!jumps) return ctx->status;

@@ -149,6 +149,32 @@ class InputStaging:
             f.result()
 
 
+# Inputs whose unit factor the library applies on the device after the upload (include/rrtmg_hip.h: pressure_scale,
+# water_path_scale) instead of this package on the host: the stand-in for sympl's extraction (_sympl_compat._extract) hands
+# them over unconverted with the factor in state["_unit_factors"].  (With the real sympl the arrays arrive converted and the
+# dictionary is absent: nothing to do.)
+_PRESSURES = ("air_pressure", "air_pressure_on_interface_levels")
+_WATER_PATHS = ("mass_content_of_cloud_ice_in_atmosphere_layer", "mass_content_of_cloud_liquid_water_in_atmosphere_layer")
+UNIT_FACTOR_ON_DEVICE = _PRESSURES + _WATER_PATHS
+
+
+def library_scales(state):
+    """The scale arguments of a host-pointer library call for the raw state of array_call: pressure_scale / water_path_scale
+    from the unit factors left unapplied (one factor per pair of arrays -- a state with, say, the two pressures in different
+    units gets them converted here), and the water-vapour mass -> volume mixing ratio (util.py:86: q * 28.964 / 18.02)."""
+    factors = state.get("_unit_factors") or {}
+    scales = {"h2o_mul": 28.964, "h2o_div": 18.02}
+    for names, key in ((_PRESSURES, "pressure_scale"), (_WATER_PATHS, "water_path_scale")):
+        f = [factors.get(n) for n in names]
+        if f[0] is not None and f[0] == f[1]:
+            scales[key] = f[0]
+        else:
+            for n, fac in zip(names, f):
+                if fac is not None:
+                    state[n] = state[n] * fac
+    return scales
+
+
 def output_arrays(pool, output_properties, raw_input_state, input_properties):
     """initialize_numpy_arrays_with_properties with recycling (OutputPool): shapes from the dims of the extracted inputs."""
     lengths = {}

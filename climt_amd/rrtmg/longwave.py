@@ -15,7 +15,7 @@ import numpy as np
 
 from .._sympl_compat import TendencyComponent, get_constant
 from .._util import ensure_contiguous_state
-from .common import (InputStaging, OutputPool, make_context, output_arrays, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict, rrtmg_cloud_overlap_method_dict,
+from .common import (UNIT_FACTOR_ON_DEVICE, InputStaging, library_scales, OutputPool, make_context, output_arrays, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict, rrtmg_cloud_overlap_method_dict,
                      rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
 
@@ -32,6 +32,7 @@ class RRTMGLongwave(TendencyComponent):
     num_longwave_bands = 16
     num_reduced_g_intervals = 140
     rrtm_iplon = 1
+    _unit_factor_on_device = UNIT_FACTOR_ON_DEVICE   # (see common.library_scales)
 
     input_properties = {
         "air_pressure": _prop(_ML, "mbar"),
@@ -129,8 +130,10 @@ class RRTMGLongwave(TendencyComponent):
     @ensure_contiguous_state
     def array_call(self, state):
         """Longwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
-        # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02, formed in four pieces in the background (common.InputStaging)
-        Q = self._input_staging.scaled("h2ovmr", state["specific_humidity"], 28.964, 18.02, pieces=4)
+        # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02 and the unit factors of the pressures and cloud water paths
+        # are applied by the library on the device, after the upload (common.library_scales): no host pass over those arrays
+        scales = library_scales(state)
+        Q = state["specific_humidity"]
         n_layers, n_columns = state["air_temperature"].shape
         # calculate_interface_temperature: the log-pressure interpolation (lw/component.py:378-384) is done by the library on
         # the device (tlev = None), not by numpy here -- 4 ms of np.log per call at 128 x 64 x 60
@@ -152,7 +155,7 @@ class RRTMGLongwave(TendencyComponent):
             reice=state["cloud_ice_particle_size"], reliq=state["cloud_water_droplet_radius"],
             tauaer=state["longwave_optical_thickness_due_to_aerosol"],
             icld=self._cloud_overlap, idrv=self._calc_dflxdt, inflg=self._cloud_optics, iceflg=self._ice_props,
-            liqflg=self._liq_props,
+            liqflg=self._liq_props, **scales
         )
         if self._mcica:
             # a fresh seed on every call, drawn exactly as the reference does (lw/component.py:415-424)

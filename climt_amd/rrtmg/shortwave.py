@@ -8,7 +8,7 @@ import numpy as np
 
 from .._sympl_compat import TendencyComponent, get_constant
 from .._util import ensure_contiguous_state
-from .common import (InputStaging, OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
+from .common import (UNIT_FACTOR_ON_DEVICE, InputStaging, library_scales, OutputPool, make_context, output_arrays, rrtmg_aerosol_input_dict, rrtmg_cloud_ice_props_dict, rrtmg_cloud_liquid_props_dict,
                      rrtmg_cloud_overlap_method_dict, rrtmg_cloud_props_dict, rrtmg_random_number_dict)
 
 
@@ -25,6 +25,7 @@ class RRTMGShortwave(TendencyComponent):
     """The Rapid Radiative Transfer Model (RRTMG), shortwave, on AMD MI355X."""
 
     num_shortwave_bands = 14
+    _unit_factor_on_device = UNIT_FACTOR_ON_DEVICE   # (see common.library_scales)
     num_ecmwf_aerosols = 6
     num_reduced_g_intervals = 112
     rrtm_iplon = 1
@@ -136,8 +137,10 @@ class RRTMGShortwave(TendencyComponent):
     @ensure_contiguous_state
     def array_call(self, state):
         """Shortwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
-        # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02, formed in four pieces in the background (common.InputStaging)
-        Q = self._input_staging.scaled("h2ovmr", state["specific_humidity"], 28.964, 18.02, pieces=4)
+        # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02 and the unit factors of the pressures and cloud water paths
+        # are applied by the library on the device, after the upload (common.library_scales): no host pass over those arrays
+        scales = library_scales(state)
+        Q = state["specific_humidity"]
         assert state["air_pressure"].shape[0] + 1 == state["air_pressure_on_interface_levels"].shape[0]
         # (the reference also interpolates interface temperatures here, sw/component.py:492-496; RRTMG_SW never reads them)
         Tint = None
@@ -163,7 +166,7 @@ class RRTMGShortwave(TendencyComponent):
             bndsolvar=self._solar_var_by_band, indsolvar=self._fac_sunspot_coeff,
             icld=self._cloud_overlap, iaer=self._aerosol_type, inflg=self._cloud_optics, iceflg=self._ice_props,
             liqflg=self._liq_props, dyofyr=day_of_year, isolvar=self._solar_var_flag, scon=float(self._solar_const),
-            adjes=state["flux_adjustment_for_earth_sun_distance"].item(), solcycfrac=state["solar_cycle_fraction"].item(),
+            adjes=state["flux_adjustment_for_earth_sun_distance"].item(), solcycfrac=state["solar_cycle_fraction"].item(), **scales
         )
         if self._mcica:
             # a fresh seed on every call, drawn exactly as the reference does (sw/component.py:537-545)

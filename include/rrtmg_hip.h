@@ -196,6 +196,12 @@ typedef struct rrtmg_sw_args {
   const double *cldfmcl;
   /* outputs */
   double *swuflx, *swdflx, *swhr, *swuflxc, *swdflxc, *swhrc;
+  /* Unit factors for HOST arrays (memspace 0), applied by the library on the device after the upload instead of by the
+   * caller on the host; 0 = the array is in the unit of the reference already.  play, plev *= pressure_scale (Pa -> mbar:
+   * 0.01); cicewp, cliqwp *= water_path_scale (kg m^-2 -> g m^-2: 1000); h2ovmr = h2ovmr * h2o_mul / h2o_div (specific
+   * humidity -> volume mixing ratio: 28.964 / 18.02, climt/_core/util.py:86).  One rounding per operation, as numpy.
+   * A struct that was zero-initialised gets none of it. */
+  double pressure_scale, water_path_scale, h2o_mul, h2o_div;
 } rrtmg_sw_args;
 
 int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a);
@@ -222,6 +228,7 @@ typedef struct rrtmg_lw_args {
   const double *cldfmcl;                             /* optional [nlay][ncol][140] mask */
   double *uflx, *dflx, *hr, *uflxc, *dflxc, *hrc;
   double *duflx_dt, *duflxc_dt;                      /* idrv==1 only, [nlay+1][ncol] */
+  double pressure_scale, water_path_scale, h2o_mul, h2o_div;   /* see rrtmg_sw_args */
 } rrtmg_lw_args;
 
 int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a);

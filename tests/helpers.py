@@ -43,11 +43,20 @@ def _fill(a, inp, fields, flags, keep):
     for k, f in flags.items():
         if k in inp:
             setattr(a, f, int(inp[k]))
+    # the unit factors the library applies on the device (rrtmg_host_inputs.h) are applied here with numpy -- the same
+    # operations, one rounding each
+    scale = {"play": ("pressure_scale",), "plev": ("pressure_scale",), "cicewp": ("water_path_scale",), "cliqwp": ("water_path_scale",),
+             "h2o": ("h2o_mul", "h2o_div")}
     for k, f in fields.items():
         v = inp.get(k)
         if v is None:
             continue
         arr = np.ascontiguousarray(v, dtype=np.float64)
+        names = scale.get(k)
+        if names and inp.get(names[0]):
+            arr = arr * float(inp[names[0]])
+            if len(names) > 1 and inp.get(names[1]):
+                arr = arr / float(inp[names[1]])
         keep.append(arr)
         setattr(a, f, arr.ctypes.data)
 

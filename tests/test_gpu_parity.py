@@ -288,6 +288,68 @@ def test_all_zero_band_arrays_are_not_sent_and_count_as_zeros(gpu_ctx):
     both("sw", one)
 
 
+def test_uniform_host_arrays_are_filled_on_the_device_and_unit_factors_applied_there(gpu_ctx):
+    """rrtmg_host_inputs.h: a host array that holds ONE value (the well-mixed gases of most models) is not uploaded -- a kernel
+    fills the device buffer, and not even that when the buffer still holds the same fill -- and the unit factors of the
+    pressures, cloud water paths and the water-vapour mixing ratio are applied on the device after the upload.  All of it
+    must be invisible: the same bits as the device-pointer path, which uploads what it is given, converted with numpy --
+    with uniform arrays, with ONE deviating element anywhere (head, between the probes, the very end), across calls that change
+    the value, make the array non-uniform and uniform again."""
+    from climt_amd import _hip
+    from climt_amd._lib import LW_OUT, SW_OUT
+    from climt_amd.synthetic import make_columns
+    N, L = 4096, 40     # 163 840 values per array: above kScanMin (131 072)
+    c = make_columns(N, L, cloudy=True, seed=21); c.update(BASE); c.pop("lat", None)
+    c["cldfr"] = (c["cldfr"] > 0.3).astype(float)
+    for k in ("cfc11", "cfc12", "cfc22", "ccl4"):
+        c[k] = np.full((L, N), {"cfc11": 0.25e-9, "cfc12": 0.5e-9, "cfc22": 0.1e-9, "ccl4": 0.1e-9}[k])
+
+    def reference(which, inp):
+        """device-pointer path on arrays converted with numpy"""
+        fluxes, outs = (gpu_ctx.sw_fluxes, SW_OUT) if which == "sw" else (gpu_ctx.lw_fluxes, LW_OUT)
+        conv = {k: v for k, v in inp.items() if k not in ("pressure_scale", "water_path_scale", "h2o_mul", "h2o_div")}
+        if inp.get("pressure_scale"):
+            conv["play"], conv["plev"] = inp["play"] * inp["pressure_scale"], inp["plev"] * inp["pressure_scale"]
+        if inp.get("water_path_scale"):
+            conv["cicewp"], conv["cliqwp"] = inp["cicewp"] * inp["water_path_scale"], inp["cliqwp"] * inp["water_path_scale"]
+        if inp.get("h2o_mul"):
+            conv["h2o"] = inp["h2o"] * inp["h2o_mul"] / inp["h2o_div"]
+        dev = {k: _hip.DeviceArray.from_host(v) for k, v in conv.items() if isinstance(v, np.ndarray)}
+        args = {k: v.ptr for k, v in dev.items()}
+        args.update({k: v for k, v in conv.items() if not isinstance(v, np.ndarray)}); args.update(ncol=N, nlay=L)
+        out = {k: _hip.DeviceArray((L + lev, N)) for k, lev in outs}
+        fluxes(args, out={k: v.ptr for k, v in out.items()}, memspace=1)
+        return {k: v.download().reshape(L + lev, N) for (k, lev), v in zip(outs, out.values())}
+
+    def same(which, inp, note):
+        host = (gpu_ctx.sw_fluxes if which == "sw" else gpu_ctx.lw_fluxes)(inp)
+        ref = reference(which, inp)
+        assert all(np.array_equal(host[k], ref[k]) for k in ref), (which, note)
+        return host
+
+    for which in ("lw", "sw"):
+        base = same(which, c, "uniform gases")
+        # the value changes from call to call (the buffer's remembered fill must not be trusted), and comes back
+        for co2 in (660e-6, 330e-6, 660e-6):
+            r = same(which, dict(c, co2=np.full((L, N), co2)), "co2 %g" % co2)
+        assert not np.array_equal(r["uflx" if which == "lw" else "swdflx"], base["uflx" if which == "lw" else "swdflx"])
+        # one deviating element: in the head, between the probed places, at the very end -> the array goes up as it is
+        for where in (7, 2048 + 13, (L * N) // 32 + 5, L * N - 1):
+            o2 = np.full((L, N), 0.21); o2.reshape(-1)[where] = 0.18
+            same(which, dict(c, o2=o2), "o2 deviates at %d" % where)
+        same(which, c, "uniform again after a non-uniform call")
+        # -0.0 is not +0.0 bitwise: such an array is simply uploaded
+        same(which, dict(c, ch4=np.full((L, N), -0.0)), "negative zeros")
+        # unit factors on the device: state units (Pa, kg m^-2, kg/kg) in, the library converts
+        raw = dict(c, play=c["play"] * 100.0, plev=c["plev"] * 100.0, cicewp=c["cicewp"] / 1000.0, cliqwp=c["cliqwp"] / 1000.0,
+                   h2o=c["h2o"] * 18.02 / 28.964, pressure_scale=0.01, water_path_scale=1000.0, h2o_mul=28.964, h2o_div=18.02)
+        r = same(which, raw, "unit factors")
+        assert max(maxdiff(r[k], base[k]) for k in base) <= 1e-6      # (the round trip through other units moves last places)
+        # ... also when the scaled arrays are uniform (the fill value is converted on the host with the same operations)
+        uni = dict(raw, cicewp=np.full((L, N), 0.02), cliqwp=np.full((L, N), 0.0), h2o=np.full((L, N), 3.0e-6))
+        same(which, uni, "uniform scaled arrays")
+
+
 def test_error_status_instead_of_stop(gpu_ctx):
     from climt_amd._lib import RRTMGError
     c, _, _ = load_ref_case("overcast_L60")
