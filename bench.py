@@ -11,8 +11,9 @@ columns that is already resident in HBM.  Workload (per GPU; columns shard embar
 
 For N>1 the output arrays are reassembled with RCCL (north_star): climt_amd.distributed.ShardedRadiation, librccl bound
 through ctypes, all-gather of one flat double-buffered device buffer on its own stream (`--gather all|root|none`); the
-gather is inside the timed region.  torch is used ONLY for the launch contract (process group, barrier, max over ranks) and
-as a fallback communicator if librccl cannot be initialised; the compute path is librrtmg_hip.so through ctypes.
+gather is inside the timed region.  torch is used ONLY for the launch contract (process group, barrier, max over ranks); the
+compute path is librrtmg_hip.so and the communicator librccl.so, both through ctypes (if librccl cannot be brought up on every
+rank the run goes on without the gather and the line says so; `--comm torch` is a testing option, tests/torch_comm.py).
 
 `python bench.py --gpus N` with N > 1 and no launcher (no WORLD_SIZE in the environment) starts the N ranks itself, one process
 per GPU, exactly as the driver's `torch.distributed.run` line would; it refuses to run when the box has fewer GPUs.
@@ -49,7 +50,9 @@ CONSTANTS = dict(pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852
 CPDAIR = 1004.64
 HBM_PEAK = 8.0e12
 HBM_SUSTAINED = 6.3e12     # what a streaming kernel achieves on this part (MI355X_MICROARCH.md; the flux kernels reach 4.3-4.5e12)
-FP64_PEAK = 78.6e12     # vector FP64, MI355X_MICROARCH.md
+# vector FP64: AMD's MI355X specification (78.6 TFLOP/s) = 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 flop x 2.4 GHz -- the CU count
+# and clock are in MI355X_MICROARCH.md, the per-SIMD FP64 rate (a wavefront's FP64 FMA issues over 4 cycles) is AMD's CDNA figure
+FP64_PEAK = 78.6e12
 FLAGS = dict(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
 
 
@@ -79,26 +82,36 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(nlay, cloudy):
-    """Reference (or port) on the host cores; bounded sample, about 10-30 s of CPU work."""
+    """Reference (or port) on ALL host cores of this box (os.cpu_count() processes: the Fortran is serial and keeps
+    process-global state), a bounded sample of about 10-30 s of CPU work per process; the 16-process figure of the earlier
+    rounds' lines is measured beside it (`with_16_processes`)."""
     import multiprocessing as mp
     try:
         from oracle import ref_driver
         kind = "reference" if (ref_driver.available("sw") and ref_driver.available("lw")) else "port"
     except Exception:
         kind = "port"
-    cores = max(1, min(os.cpu_count() or 1, 16))
     per = 256 if not cloudy else 96
-    reps = int((96 if not cloudy else 48) * 60 / nlay) or 1      # ~10-20 s of CPU work per process
-    try:
+
+    def run(cores, reps):
         ctx = mp.get_context("spawn")
         with ctx.Pool(cores) as pool:
             t0 = time.perf_counter()
             times = pool.map(_cpu_worker, [(kind, per, nlay, cloudy, 1000 + i, reps) for i in range(cores)])
             wall = time.perf_counter() - t0
-        v = cores * per * reps / max(times)      # the timed compute regions run concurrently on `cores` processes
-        return {"value": v, "unit": "columns/s", "cores": cores, "kind": kind,
-                "sample": "%d processes x %d calls x %d synthetic columns x %d levels, LW+SW %s; compute region max %.2f s (pool wall %.1f s); "
-                          "LW on synthetic k-tables" % (cores, reps, per, nlay, "McICA" if cloudy else "clear-sky", max(times), wall)}
+        # the timed compute regions run concurrently on `cores` processes
+        return cores * per * reps / max(times), max(times), wall
+    all_cores = max(1, os.cpu_count() or 1)
+    reps = int((96 if not cloudy else 48) * 60 / nlay) or 1      # ~10-20 s of CPU work per process
+    try:
+        v, tmax, wall = run(all_cores, max(1, reps // 2) if all_cores > 16 else reps)
+        out = {"value": v, "unit": "columns/s", "cores": all_cores, "kind": kind,
+               "sample": "%d processes (os.cpu_count()) x %d calls x %d synthetic columns x %d levels, LW+SW %s; compute region max %.2f s (pool wall %.1f s); "
+                         "LW on synthetic k-tables" % (all_cores, max(1, reps // 2) if all_cores > 16 else reps, per, nlay, "McICA" if cloudy else "clear-sky", tmax, wall)}
+        if all_cores > 16:
+            v16, t16, w16 = run(16, reps)
+            out["with_16_processes"] = {"value": v16, "cores": 16, "sample": "16 processes x %d calls x %d columns; compute region max %.2f s" % (reps, per, t16)}
+        return out
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "columns/s", "cores": 0, "kind": kind, "sample": "cpu baseline failed: %r" % (e,)}
 
@@ -110,53 +123,15 @@ def _profile_json(name):
         return {}
 
 
-class _TorchBuf:
-    """A device buffer owned by torch (fallback communicator): the same .ptr / .download() as _hip.DeviceArray."""
+class _NoComm:
+    """What is left when librccl could not be brought up on every rank: no gather (the line says so), compute still measured."""
+    kind, stream = "none", None
 
-    def __init__(self, shape, device):
-        import torch
-        self.t = torch.empty(int(np.prod(shape)), dtype=torch.float64, device=device)
-        self.ptr = self.t.data_ptr()
-
-    def download(self):
-        return self.t.cpu().numpy()
-
-
-class _TorchDeviceComm:
-    """Fallback for N>1 when librccl cannot be initialised directly: torch.distributed (backend nccl = RCCL) on buffers
-    that torch allocated; same interface as climt_amd.distributed.RcclComm."""
-
-    def __init__(self, dist, rank, world, device):
-        import torch
-        self.dist, self.rank, self.world, self.device = dist, rank, world, device
-        self.bufs, self.work = {}, []
-        self.kind = "torch." + dist.get_backend()
-
-        class _S:      # the library's kernels are waited for on the host in this fallback (no foreign stream handle)
-            s = None
-        self.stream = _S()
-        self.torch = torch
-
-    def alloc(self, shape):
-        b = _TorchBuf(shape, self.device)
-        self.bufs[b.ptr] = b.t
-        return b
-
-    def all_gather(self, send_ptr, recv_ptr, count):
-        self.work.append(self.dist.all_gather_into_tensor(self.bufs[recv_ptr], self.bufs[send_ptr][:count], async_op=True))
-
-    def gather_root(self, send_ptr, recv_ptr, count):
-        if self.rank == 0:
-            parts = list(self.bufs[recv_ptr].view(self.world, count).unbind(0))
-            self.work.append(self.dist.gather(self.bufs[send_ptr][:count], parts, dst=0, async_op=True))
-        else:
-            self.work.append(self.dist.gather(self.bufs[send_ptr][:count], None, dst=0, async_op=True))
+    def __init__(self, rank, world):
+        self.rank, self.world = rank, world
 
     def wait(self):
-        for w in self.work:
-            w.wait()
-        self.work = []
-        self.torch.cuda.synchronize()
+        pass
 
     def close(self):
         pass
@@ -208,7 +183,7 @@ def main():
     ap.add_argument("--lw-first", action="store_true", help="enqueue the longwave before the shortwave (N=1; experiment)")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
     ap.add_argument("--sync-every-step", action="store_true", help="host synchronize after every step inside the timed brackets too (N=1)")
-    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default) or torch.distributed")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "torch"], help="N>1 communicator: librccl via ctypes (default); torch = testing only (tests/torch_comm.py)")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the launch contract (nccl = RCCL)")
     ap.add_argument("--share-device", action="store_true", help="testing: every rank uses GPU 0 (2 ranks on a 1-GPU box; with --dist-backend gloo)")
     ap.add_argument("--force-dist", action="store_true", help="testing: run the N>1 code path (communicator, gather) with a single rank too")
@@ -384,7 +359,7 @@ def main():
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
             # communicator + one small all-gather end to end, under a watchdog: a bootstrap that never returns must cost
-            # a fallback to torch.distributed, not the run
+            # the gather (the line says so), not the run
             import threading
             box = {}
 
@@ -412,9 +387,18 @@ def main():
             if int(ok.item()) == 0:
                 comm = None
         alloc = None
-        if comm is None:
-            comm = _TorchDeviceComm(dist, rank, world, "cuda:%d" % local)
+        if comm is None and a.comm == "torch":
+            # TESTING only (two ranks on one GPU, where RCCL refuses): a communicator over torch.distributed on torch-owned
+            # buffers, from the test infrastructure -- the product path is librccl through ctypes (climt_amd.distributed.RcclComm)
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from torch_comm import TorchDeviceComm
+            comm = TorchDeviceComm(dist, rank, world, "cuda:%d" % local)
             alloc = comm.alloc
+        elif comm is None:
+            if a.gather != "none":
+                comm_note += "no output gather in this run; "
+            a.gather = "none"
+            comm = _NoComm(rank, world)
         comm_kind = comm.kind
         sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist, unpack=not a.no_unpack)
         if a.serial:
@@ -499,6 +483,15 @@ def main():
     if rank == 0:
         mode = "cloudy" if cloudy else "clear"
         traffic_json, flops_json = _profile_json("hbm_traffic.json"), _profile_json("fp64_flops.json")
+        # the committed counters are quoted only for the library they were measured on (hash of csrc + the header, compiled in)
+        from climt_amd._lib import source_hash
+        lib_hash = source_hash()
+        counters_note = None
+        if traffic_json.get("source_hash") != lib_hash:
+            counters_note = ("profiles/hbm_traffic.json was measured on sources %s, this library is built from %s: traffic / flops not quoted "
+                             "(re-run the PMC passes: tools/gpu_session.sh <round> pmc pmclarge sq; tools/make_traffic_json.py <round>)"
+                             % (traffic_json.get("source_hash"), lib_hash))
+            traffic_json, flops_json = {}, {}
         launches = max(1, ctx.kernel_launches("sw", cloudy=cloudy))      # column chunks per call: one launch of each solve kernel per chunk
         kernels = []
         for which, first, name, bpc, timed, alone in (
@@ -564,6 +557,7 @@ def main():
                          "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
                          "fp64_frac_serial": (flops / (kms_serial * 1e-3) / FP64_PEAK) if flops else None,
                          "host_call_ms": {"sw": r["enq_sw"], "sw+lw": r["enq"]},
+                         "library_source_hash": lib_hash, "counters_source_hash": traffic_json.get("source_hash"), "counters_note": counters_note,
                          "note": "kernel = the solve kernel that takes longer with the GPU to itself (also the larger share in profiles/*_kernel_stats.txt); "
                                  "achieved = its ALGORITHMIC bytes per launch / kernel_ms (HIP events around its launches, average over the launches "
                                  "of a call; duration_source says whether that is the timed region or the kernel alone); kernels[] has both solve "
@@ -590,6 +584,22 @@ def main():
                                       "ms_per_step": m["ms"], "ms_per_step_median": float(np.median(m["per"])), "steps": st,
                                       "sw_solve_cloudy_ms": float(np.mean(m["ksw"])), "lw_solve_cloudy_ms": float(np.mean(m["klw"])),
                                       "sw_solve_cloudy_ms_serial": float(np.mean(m["ssw"])), "lw_solve_cloudy_ms_serial": float(np.mean(m["slw"]))}
+                    # the same roofline block for this configuration: dominant kernel = the cloudy solve kernel that takes longer alone
+                    mk = []
+                    for name, bpc, alone in (("rrtmg::sw_solve_cloudy_kernel", (34 * 60 + 11) * 8, float(np.mean(m["ssw"]))),
+                                             ("rrtmg::lw_solve_all_kernel<true, false>", (56 * 60 + 22) * 8, float(np.mean(m["slw"])))):
+                        tr, fl = traffic_json.get("%s|8192|60|cloudy" % name), flops_json.get("%s|8192|60|cloudy" % name)
+                        mk.append({"kernel": name, "launch_ms_alone": alone, "algorithmic_bytes_per_launch": bpc * 8192,
+                                   "achieved_GBps_alone": bpc * 8192 / (alone * 1e-3) / 1e9, "frac_alone": bpc * 8192 / (alone * 1e-3) / HBM_PEAK,
+                                   "traffic_per_launch": tr, "fp64_flops_per_launch": fl,
+                                   "fp64_frac_alone": (fl / (alone * 1e-3) / FP64_PEAK) if fl else None})
+                    md = max(mk, key=lambda k: k["launch_ms_alone"])
+                    st_tr = traffic_json.get("step|8192|60|cloudy")
+                    extra["mcica"]["roofline"] = {"bound": "hbm", "kernel": md["kernel"], "achieved": md["achieved_GBps_alone"], "peak": HBM_PEAK / 1e9,
+                                                  "unit": "GB/s", "frac": md["frac_alone"], "traffic": md["traffic_per_launch"],
+                                                  "fp64_frac": md["fp64_frac_alone"], "kernels": mk, "step_traffic": st_tr,
+                                                  "step_hbm_side_frac": (st_tr / (m["ms"] * 1e-3) / HBM_SUSTAINED) if st_tr else None,
+                                                  "duration_source": "alone"}
                 # (b) end to end including PCIe: host-pointer C-ABI (H2D of every input, D2H of the 12 outputs per call)
                 try:
                     c = r["c"]

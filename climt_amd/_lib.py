@@ -124,6 +124,12 @@ SW_OUT = (("swuflx", 1), ("swdflx", 1), ("swhr", 0), ("swuflxc", 1), ("swdflxc",
 LW_OUT = (("uflx", 1), ("dflx", 1), ("hr", 0), ("uflxc", 1), ("dflxc", 1), ("hrc", 0))
 
 
+def source_hash():
+    """The hash of the sources the loaded library was built from (rrtmg_hip_version(): "... src:<16 hex digits>")."""
+    v = load_library().rrtmg_hip_version().decode()
+    return v.split("src:")[1].strip() if "src:" in v else "unknown"
+
+
 def _locked(fn):
     """Context methods that enter the library hold the context's lock: ctypes releases the GIL for the duration of a
     call, and a context -- its staging buffers, work-buffer map, error string, streams -- is shared by every component of

@@ -19,6 +19,19 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over every file of climt_amd/csrc and include/rrtmg_hip.h, names and contents: what the
+    library was built from.  Compiled into rrtmg_hip_version() and written into every profile under profiles/ (tools/
+    gpu_session.sh), so that bench.py can tell whether the committed HBM-traffic counters were measured on the library that runs."""
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "include", "rrtmg_hip.h")]
+    for f in files:
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode() + b"\0")
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=True):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
     hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "rrtmg_hip.h")]
@@ -26,6 +39,7 @@ def build(force=False, verbose=True):
     extra = os.environ.get("RRTMG_HIP_BUILD_FLAGS", "").split()
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest(srcs + hdrs):
         return out
+    src_hash = source_hash()
     os.makedirs(os.path.dirname(out), exist_ok=True)
     objdir = os.path.join(HERE, "_lib", "obj-" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:8])
     os.makedirs(objdir, exist_ok=True)
@@ -34,9 +48,11 @@ def build(force=False, verbose=True):
     for src in srcs:
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
+        # rrtmg_abi.hip carries the source hash (rrtmg_hip_version): it is compiled whenever anything is
+        stale = os.path.basename(src) == "rrtmg_abi.hip"
+        if not force and not stale and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), newest_hdr):
             continue
-        cmd = BASE + extra + ["-c", src, "-o", obj]
+        cmd = BASE + extra + (['-DRRTMG_SRC_HASH="%s"' % src_hash] if stale else []) + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         jobs.append((cmd, subprocess.Popen(cmd)))

@@ -254,7 +254,11 @@ using namespace rrtmg;
 
 extern "C" {
 
-const char *rrtmg_hip_version(void) { return "rrtmg-hip 0.1 (gfx950)"; }
+#ifndef RRTMG_SRC_HASH
+#define RRTMG_SRC_HASH "unknown"
+#endif
+// "... src:<hash>": sha256 over climt_amd/csrc + include/rrtmg_hip.h at build time (climt_amd/build.py::source_hash)
+const char *rrtmg_hip_version(void) { return "rrtmg-hip 0.2 (gfx950) src:" RRTMG_SRC_HASH; }
 
 int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   if (!out) return RRTMG_ERR_ARG;

@@ -13,13 +13,16 @@ exchanged while computing.  The only communication reassembles the outputs, and 
 
 `RcclComm` binds librccl.so directly (ctypes: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv) and
 runs on its own HIP stream, which is made to wait for the radiation kernels on the device (rrtmg_hip_stream_wait): the gather
-of step i runs under the kernels of step i+1, into the other half of a double buffer.  `TorchComm` carries the same interface
-over torch.distributed on host memory -- the world-size-2 gloo tests on CPU, and a fallback if RCCL cannot be initialised.
+of step i runs under the kernels of step i+1, into the other half of a double buffer.  Any object with the same five methods
+can stand in for it: the world-size-2 CPU tests use one over torch.distributed's gloo (tests/torch_comm.py) -- this package
+itself imports no torch.
 
-Sharded == unsharded, bit for bit: kissvec sub-columns are seeded per column; for the Mersenne twister, whose reference stream
-is ONE sequence over (sub-column, column, layer), every rank passes its block's position (shard_col0, shard_ncol) and the
-generator starts at the rank's own draws (jump-ahead, csrc/rrtmg_mt_device.hip).  When a block boundary is not a multiple of the 64-column tile, a column
-may run the other solve-kernel variant (clear-sky / cloudy tile), which changes the shortwave by round-off only.
+Sharded == unsharded, bit for bit, for ANY number of columns and ranks: kissvec sub-columns are seeded per column; for the
+Mersenne twister, whose reference stream is ONE sequence over (sub-column, column, layer), every rank passes its block's
+position (shard_col0, shard_ncol) and the generator starts at the rank's own draws (jump-ahead, csrc/rrtmg_mt_device.hip); and
+block boundaries are multiples of the 64-column tile (column_block(align=64)), so that every column runs in the same tile --
+and therefore in the same solve-kernel variant (clear-sky / cloudy tile) -- as in the unsharded call.  (A boundary inside a
+tile could move a column to the other variant, which changes the shortwave by round-off.)
 """
 import ctypes as C
 import os
@@ -42,11 +45,18 @@ COLUMN_AXIS = dict(
 )
 
 
-def column_block(ncol, world, rank):
-    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one column."""
-    base, rem = divmod(ncol, world)
+TILE = 64   # columns of a wavefront tile (csrc: one wavefront = 64 columns x one work item)
+
+
+def column_block(ncol, world, rank, align=TILE):
+    """Contiguous block [lo, hi) of rank `rank`.  Boundaries are multiples of `align` columns (the last block ends at ncol):
+    the tiles are dealt out, blocks differ by at most one tile -- a rank may get nothing when there are fewer tiles than ranks.
+    align=1: blocks that differ by at most one column."""
+    ntile = -(-ncol // align)
+    base, rem = divmod(ntile, world)
     lo = rank * base + min(rank, rem)
-    return lo, lo + base + (1 if rank < rem else 0)
+    hi = lo + base + (1 if rank < rem else 0)
+    return min(ncol, lo * align), min(ncol, hi * align)
 
 
 def slice_columns(inp, lo, hi):
@@ -190,39 +200,6 @@ class RcclComm:
             self.comm = None
 
 
-class TorchComm:
-    """The same interface over torch.distributed on HOST arrays (numpy): gloo in the CPU tests."""
-
-    def __init__(self, dist, rank, world):
-        self.dist, self.rank, self.world = dist, rank, world
-        self.stream = None
-        self.kind = "torch." + dist.get_backend()
-
-    def all_gather(self, send, recv, count):
-        import torch
-        parts = [torch.empty(count, dtype=torch.float64) for _ in range(self.world)]
-        self.dist.all_gather(parts, torch.from_numpy(send[:count]))
-        for r, p in enumerate(parts):
-            recv[r * count:(r + 1) * count] = p.numpy()
-
-    def gather_root(self, send, recv, count):
-        import torch
-        t = torch.from_numpy(send[:count])
-        if self.rank == 0:
-            parts = [torch.empty(count, dtype=torch.float64) for _ in range(self.world)]
-            self.dist.gather(t, parts, dst=0)
-            for r in range(1, self.world):
-                recv[r * count:(r + 1) * count] = parts[r].numpy()
-        else:
-            self.dist.gather(t, None, dst=0)
-
-    def wait(self):
-        pass
-
-    def close(self):
-        pass
-
-
 # ---- the sharded radiation step ----------------------------------------------------------------------------------
 class ShardedRadiation:
     """This rank's block of a column grid, resident on its GPU, and the (double-buffered) gather of the outputs.
@@ -235,7 +212,8 @@ class ShardedRadiation:
     `ctx` is a climt_amd._lib.Context (device memory) -- or the tests' host emulation, in which case the buffers are numpy.
     """
 
-    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2, allocator=None, force=False, unpack=False):
+    def __init__(self, ctx, comm, ncol_total, nlay, gather="all", idrv=False, device=True, nbuf=2, allocator=None, force=False, unpack=False,
+                 align=TILE):
         """unpack=True: on the ranks that hold the gathered outputs they are also put into the BOUNDARY layout -- every array
         [levels][ncol_total], column fastest, as a single-GPU call would have written it (rrtmg_lw_c_binder.f90:198-202) -- by
         a block-copy kernel behind the gather on the communicator's stream (rrtmg_hip_copy_blocks): gathered_device(b) /
@@ -246,9 +224,11 @@ class ShardedRadiation:
         self.ctx, self.comm, self.gather, self.device = ctx, comm, gather, device
         self.rank, self.world = comm.rank, comm.world
         self.ncol_total, self.nlay = ncol_total, nlay
-        self.lo, self.hi = column_block(ncol_total, self.world, self.rank)
+        self.align = align
+        self.lo, self.hi = column_block(ncol_total, self.world, self.rank, align)
         self.ncol = self.hi - self.lo
-        self.width = -(-ncol_total // self.world)          # widest block: the per-rank stride of the gathered buffer
+        # widest block: the per-rank stride of the gathered buffer
+        self.width = max(hi - lo for lo, hi in (column_block(ncol_total, self.world, r, align) for r in range(self.world)))
         self.names = [k for k, _ in SW_OUT] + [k for k, _ in LW_OUT] + (["duflx_dt", "duflxc_dt"] if idrv else [])
         self.levs = [lev for _, lev in SW_OUT] + [lev for _, lev in LW_OUT] + ([1, 1] if idrv else [])
         self.idrv = idrv
@@ -292,7 +272,7 @@ class ShardedRadiation:
         dst = self.boundary_offsets()
         out = []
         for r in range(self.world):
-            rlo, rhi = column_block(self.ncol_total, self.world, r)
+            rlo, rhi = column_block(self.ncol_total, self.world, r, self.align)
             n_r = rhi - rlo
             own = self.gather == "root" and r == self.rank
             for k, (off, rows) in self.offsets(n_r).items():
@@ -390,8 +370,9 @@ class ShardedRadiation:
             self.inflight[b] = False
         sw, lw = self._out(b)
         ms = 1 if self.device else 0
-        self.ctx.sw_fluxes(self.inp, mcica=mcica, out=sw, memspace=ms)
-        self.ctx.lw_fluxes(self.inp, mcica=mcica, out=lw, memspace=ms)
+        if self.ncol > 0:                         # (fewer tiles than ranks: this rank has no columns and only takes part in the gather)
+            self.ctx.sw_fluxes(self.inp, mcica=mcica, out=sw, memspace=ms)
+            self.ctx.lw_fluxes(self.inp, mcica=mcica, out=lw, memspace=ms)
         if self.do_gather:
             if self.device and host_wait:
                 self.ctx.synchronize()
@@ -450,7 +431,7 @@ class ShardedRadiation:
         mine = self.local_host(b)
         cols = {k: [] for k in self.names}
         for r in range(self.world):
-            rlo, rhi = column_block(self.ncol_total, self.world, r)
+            rlo, rhi = column_block(self.ncol_total, self.world, r, self.align)
             n_r = rhi - rlo
             for k, (off, n) in self.offsets(n_r).items():
                 if r == self.rank and self.gather == "root":
@@ -458,28 +439,3 @@ class ShardedRadiation:
                 else:
                     cols[k].append(full[r * self.block + off: r * self.block + off + n * n_r].reshape(n, n_r))
         return {k: np.concatenate(v, axis=1) for k, v in cols.items()}
-
-
-def sharded_fluxes(ctx, inp, which, mcica, dist, world, rank):
-    """Convenience for host arrays: this rank's block of `inp` through ctx.{sw,lw}_fluxes, outputs all-gathered with
-    torch.distributed; returns full-size arrays on every rank.  (The device-resident path is ShardedRadiation.)"""
-    nlay, ncol = inp["play"].shape
-    lo, hi = column_block(ncol, world, rank)
-    local = slice_columns(inp, lo, hi)
-    local.update(shard_col0=lo, shard_ncol=ncol)
-    out = ctx.sw_fluxes(local, mcica=mcica) if which == "sw" else ctx.lw_fluxes(local, mcica=mcica)
-    comm = TorchComm(dist, rank, world)
-    width = -(-ncol // world)
-    full = {}
-    for k, v in out.items():
-        count = v.shape[0] * width
-        send = np.zeros(count)
-        send[: v.size] = v.ravel()
-        recv = np.zeros(count * world)
-        comm.all_gather(send, recv, count)
-        cols = []
-        for r in range(world):
-            rlo, rhi = column_block(ncol, world, r)
-            cols.append(recv[r * count: r * count + v.shape[0] * (rhi - rlo)].reshape(v.shape[0], rhi - rlo))
-        full[k] = np.concatenate(cols, axis=1)
-    return full

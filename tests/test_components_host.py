@@ -111,6 +111,22 @@ def test_change_up_flux_arrays_are_not_overwritten_by_the_next_call():
     assert maxdiff(lw.change_in_upward_flux_with_surface_temperature, snapshot) > 0.0
 
 
+def test_config1_radiative_equilibrium_loop_on_the_host_emulation():
+    """BASELINE configs[0] as far as a GPU-less container goes: examples/radiative_equilibrium.py (the reference's
+    examples/radiative_equilibrium_rrtmg.py:43-66 with `from climt_amd import ...`) for six steps on the host emulation of the
+    device functions; step 0's shortwave diagnostics are the reference's TestRRTMGShortwave-column cache (1e-8)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("radiative_equilibrium", os.path.join(ROOT, "examples", "radiative_equilibrium.py"))
+    ex = importlib.util.module_from_spec(spec); spec.loader.exec_module(ex)
+    first, end = ex.run(6, device_resident=False)
+    _, _, cache_diag = load_cache_case("TestRRTMGShortwave", "column")
+    for k, want in cache_diag.items():
+        g = np.transpose(first[k].values, [first[k].dims.index(x) for x in want.dims])
+        assert maxdiff(g, want.values) <= 1e-8, k
+    t = end["air_temperature"].values
+    assert np.all(np.isfinite(t)) and t.ravel()[-1] != 290.0
+
+
 def test_state_axis_permutation_invariance():
     """tests/test_components.py:291-327: reversed / transposed horizontal axes give the same answer."""
     state, _, _ = load_cache_case("TestRRTMGShortwaveMCICA", "3d")

@@ -2,7 +2,7 @@
 with the host emulation of the device functions, gather the outputs, and must reproduce the unsharded
 result bit for bit -- what the 8-GPU run relies on.  The product class under test is
 climt_amd.distributed.ShardedRadiation (flat double-buffered output buffer, gather modes all / root / none);
-on the GPU its communicator is RcclComm (librccl through ctypes), here TorchComm (gloo) on host memory."""
+on the GPU its communicator is RcclComm (librccl through ctypes), here tests/torch_comm.TorchComm (gloo) on host memory."""
 import os
 import socket
 import sys
@@ -29,8 +29,9 @@ def _cases():
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch.distributed as dist
-    from climt_amd.distributed import ShardedRadiation, TorchComm, sharded_fluxes
+    from climt_amd.distributed import ShardedRadiation
     from helpers import EmuContext
+    from torch_comm import TorchComm, sharded_fluxes
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     ctx = EmuContext()
@@ -148,14 +149,72 @@ def test_slice_columns_uses_the_axis_map_not_shapes():
 
 
 def test_column_blocks_cover_and_balance():
+    """Blocks are contiguous, cover the grid, start on tile boundaries (so that a column runs in the same 64-column tile --
+    the same solve-kernel variant -- sharded or not: bitwise shard == whole for ANY column count) and differ by at most a tile."""
     from climt_amd.distributed import column_block
-    for ncol in (1, 7, 64, 8192, 131072, 1036800):
+    for ncol in (1, 7, 64, 100, 1000, 8192, 131072, 1036800):
         for world in (1, 2, 3, 8):
-            edges = [column_block(ncol, world, r) for r in range(world)]
-            assert edges[0][0] == 0 and edges[-1][1] == ncol
-            assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
-            sizes = [hi - lo for lo, hi in edges]
-            assert max(sizes) - min(sizes) <= 1
+            for align in (64, 1):
+                edges = [column_block(ncol, world, r, align) for r in range(world)]
+                assert edges[0][0] == 0 and edges[-1][1] == ncol
+                assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+                assert all(lo % align == 0 for lo, hi in edges if hi > lo)
+                sizes = [hi - lo for lo, hi in edges]
+                tiles = [-(-n // align) for n in sizes]
+                assert max(tiles) - min(tiles) <= 1 and min(sizes) >= 0      # (the last block may also be ragged)
+    assert [column_block(1000, 3, r) for r in range(3)] == [(0, 384), (384, 704), (704, 1000)]
+    assert [column_block(100, 3, r) for r in range(3)] == [(0, 64), (64, 100), (100, 100)]      # fewer tiles than ranks
+
+
+def _worker3(rank, world, port, q):
+    """1000 columns (not a multiple of anything) over three ranks, one of the blocks ragged; 100 columns: a rank with nothing."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from climt_amd.distributed import ShardedRadiation
+    from climt_amd.synthetic import make_columns
+    from helpers import EmuContext
+    from torch_comm import TorchComm
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ctx = EmuContext()
+    res = {}
+    for ncol in (1000, 100):
+        c = make_columns(ncol, 12, cloudy=True, seed=77); c.pop("lat")
+        c.update(icld=2, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=1, permuteseed=4242)
+        sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, 12, gather="all", device=False, unpack=True)
+        sr.set_inputs(c)
+        b = sr.step(mcica=True)
+        sr.finish()
+        res[ncol] = (sr.gathered_host(b), (sr.lo, sr.hi))
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put((rank, res))
+
+
+def test_three_ranks_any_column_count_is_bit_identical():
+    """bit-identical to the 1-GPU result for a general N -- 1000 columns over 3 ranks (blocks of 384 / 320 / 296:
+    tile-aligned starts), Mersenne twister with maximum-random overlap, gather + unpack; and 100 columns (2 tiles, rank 2 idle)."""
+    import torch.multiprocessing as mp
+    from climt_amd.synthetic import make_columns
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker3, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    e = EmuContext()
+    for ncol, blocks in ((1000, [(0, 384), (384, 704), (704, 1000)]), (100, [(0, 64), (64, 100), (100, 100)])):
+        c = make_columns(ncol, 12, cloudy=True, seed=77); c.pop("lat")
+        c.update(icld=2, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=1, permuteseed=4242)
+        full = dict(e.sw_fluxes(c, mcica=True)); full.update(e.lw_fluxes(c, mcica=True))
+        for rank in range(3):
+            got, block = res[rank][ncol]
+            assert block == blocks[rank]
+            assert all(np.array_equal(got[k], full[k]) for k in full), (ncol, rank)
 
 
 def test_tcp_rendezvous_hands_out_rank0s_bytes():

@@ -954,6 +954,32 @@ def _shard_size_checks(gpu_ctx, ncol, nlay, sample, seed):
     assert all(np.array_equal(lw[k][:, perm], lwp[k]) for k in lw)
 
 
+@pytest.mark.parametrize("ncol,world", [(1000, 3), (777, 8), (100, 3)])
+def test_tile_aligned_blocks_equal_the_whole_for_any_column_count(gpu_ctx, ncol, world):
+    """SURVEY 8(e) for a general N: the blocks climt_amd.distributed.column_block deals out (tile-aligned starts) reproduce the
+    unsharded call bit for bit -- in a grid that has cloud-free AND cloudy tiles (the two solve-kernel variants), with the
+    Mersenne twister (one global stream: every block starts at its own draws) and without McICA."""
+    from climt_amd.distributed import column_block, slice_columns
+    from climt_amd.synthetic import make_columns
+    c = make_columns(ncol, 40, cloudy=True, seed=5); c.pop("lat")
+    for k in ("cldfr", "cicewp", "cliqwp"):
+        c[k][:, 64:256] = 0.0          # three cloud-free tiles in the middle, ragged cloudy ones around them
+    blocks = [column_block(ncol, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == ncol and all(lo % 64 == 0 for lo, hi in blocks if hi > lo)
+    for mcica, extra in ((True, dict(icld=2, irng=1, permuteseed=99)), (False, dict(icld=1))):
+        cc = dict(c); cc.update(BASE); cc.update(extra)
+        if not mcica:
+            cc["cldfr"] = (cc["cldfr"] > 0.3).astype(float)      # (the shortwave without McICA takes overcast or clear layers only)
+        sw, lw = gpu_ctx.sw_fluxes(cc, mcica=mcica), gpu_ctx.lw_fluxes(cc, mcica=mcica)
+        for lo, hi in blocks:
+            if hi == lo:
+                continue
+            sub = slice_columns(cc, lo, hi); sub.update(shard_col0=lo, shard_ncol=ncol)
+            s, l = gpu_ctx.sw_fluxes(sub, mcica=mcica), gpu_ctx.lw_fluxes(sub, mcica=mcica)
+            assert all(np.array_equal(sw[k][:, lo:hi], s[k]) for k in sw), (mcica, lo, hi)
+            assert all(np.array_equal(lw[k][:, lo:hi], l[k]) for k in lw), (mcica, lo, hi)
+
+
 def test_config4_shard_size_16384x60(gpu_ctx):
     """BASELINE configs[3]: 512x256x60 over 8 GPUs = 16 384 columns x 60 levels per GPU."""
     _shard_size_checks(gpu_ctx, 16384, 60, 4096, 41)
@@ -1018,6 +1044,29 @@ def test_device_resident_radiation_step_equals_the_host_path(mcica):
         assert g.shape == h.values.shape and maxdiff(g, h.values) <= 1.0e-9 * scale, (n, maxdiff(g, h.values))
     assert float(np.abs(host["air_temperature_tendency_from_shortwave"].values).max()) > 0.1      # daylight columns exist
     assert float(np.abs(host["surface_temperature"].values - 300.0).max()) > 0.0                    # the slab moved
+
+
+def test_config1_radiative_equilibrium_loop_in_both_modes():
+    """BASELINE configs[0]: the reference's examples/radiative_equilibrium_rrtmg.py:43-66 -- AdamsBashforth([rad_sw, rad_lw]), list
+    form, dt = 3 h, get_grid(nx=1, ny=1, nz=30) -- as examples/radiative_equilibrium.py, 40 steps, on a host state and on a
+    DeviceState.  The shortwave diagnostics of step 0 are the reference's TestRRTMGShortwave-column cache (1e-8, its own
+    criterion); the two modes end in the same state; the column has moved towards equilibrium (stratosphere cooler than the
+    290 K isothermal start, finite everywhere)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("radiative_equilibrium", os.path.join(ROOT, "examples", "radiative_equilibrium.py"))
+    ex = importlib.util.module_from_spec(spec); spec.loader.exec_module(ex)
+    _, _, cache_diag = load_cache_case("TestRRTMGShortwave", "column")
+    first_h, end_h = ex.run(40, device_resident=False)
+    first_d, end_d = ex.run(40, device_resident=True)
+    for first in (first_h, first_d):
+        for k, want in cache_diag.items():
+            got = first[k]
+            g = np.transpose(got.values, [got.dims.index(x) for x in want.dims])
+            assert maxdiff(g, want.values) <= 1e-8, k
+        assert "upwelling_longwave_flux_in_air" in first and "air_temperature_tendency_from_longwave" in first
+    t_h, t_d = end_h["air_temperature"].values, end_d["air_temperature"].values
+    assert np.all(np.isfinite(t_h)) and maxdiff(t_h, np.transpose(t_d, [end_d["air_temperature"].dims.index(x) for x in end_h["air_temperature"].dims])) <= 1e-9
+    assert t_h.ravel()[-1] != 290.0 and np.all((t_h > 150.0) & (t_h < 400.0))
 
 
 def test_radiation_column_example_runs_in_both_modes():
@@ -1087,7 +1136,7 @@ def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
 
 def test_copy_blocks_kernel_unpacks_a_three_rank_gather(gpu_ctx):
     """rrtmg_hip_copy_blocks with the descriptors ShardedRadiation builds for THREE ranks with unequal blocks (1000 columns:
-    334 + 333 + 333), on a gathered buffer assembled on the host: [rank][array][level][local column] ->
+    384 + 320 + 296, tile-aligned starts), on a gathered buffer assembled on the host: [rank][array][level][local column] ->
     [array][level][column], against numpy.  (One GPU: the collective itself is covered by the one-rank RCCL test and the
     two-rank gloo test; this is the multi-rank layout arithmetic on the device.)"""
     from climt_amd import _hip

@@ -7,8 +7,11 @@ export RRTMG_HIP_ALLOW_SYNTHETIC_LW=1
 R=$1; shift
 O=gpurun_out
 mkdir -p $O
-stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_stats.py $f > $2; rm -rf $1; }   # (the raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
-pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f rrtmg:: > $2; rm -rf $1; }
+# every summary starts with the hash of the sources the profiled library was built from (climt_amd/build.py::source_hash):
+# bench.py compares it with the library that runs before it quotes the counters
+HASH=$(python -c "from climt_amd._lib import source_hash; print(source_hash())" 2>/dev/null | tail -1)
+stats() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && { echo "# source_hash $HASH"; python tools/rocpd_stats.py $f; } > $2; rm -rf $1; }   # (the raw traces stay on the box: gpurun_out/ is capped at 64 MiB)
+pmc() { f=$(find $1 -name "*.db" | head -1); [ -n "$f" ] && { echo "# source_hash $HASH"; python tools/rocpd_pmc.py $f rrtmg::; } > $2; rm -rf $1; }
 for sec in "$@"; do
   echo "=== section $sec ($(date +%T))"
   case $sec in

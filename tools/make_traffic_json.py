@@ -15,14 +15,16 @@ launch of one column chunk.
              dispatches) / steps, steps = dispatches of sw_prep_fused_kernel / column chunks of a call (the preparation is
              launched once per chunk of 128 tiles = 8192 columns, the default RRTMG_HIP_CHUNK_TILES); "step_kernels|..." lists
              the terms.
-usage: tools/make_traffic_json.py [round=r03]"""
+Every PMC file starts with "# source_hash <hash>" (the sources the profiled library was built from); the passes of a round must
+agree, and the hash goes into both files: bench.py quotes the counters only for the library they were measured on.
+usage: tools/make_traffic_json.py [round=r04]"""
 import json
 import os
 import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 
 
 def get_all(fn, counter):
@@ -41,6 +43,22 @@ def get_all(fn, counter):
 def get(fn, counter):
     return {k: v[0] for k, v in get_all(fn, counter).items() if "_solve_" in k}
 
+
+def file_hash(fn):
+    try:
+        first = open(os.path.join(ROOT, "profiles", fn)).readline()
+    except OSError:
+        return None
+    return first.split()[2] if first.startswith("# source_hash") else None
+
+
+hashes = set()
+for fn in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+    if fn.startswith(rnd + "_pmc_"):
+        hashes.add(file_hash(fn))
+if len(hashes) != 1 or None in hashes:
+    sys.exit("the PMC passes of round %s were not all taken on one library (source hashes %s): nothing written" % (rnd, sorted(map(str, hashes))))
+src_hash = hashes.pop()
 
 traffic = {"_doc": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s_pmc_*; see tools/make_traffic_json.py" % rnd}
 flops = {"_doc": "FP64 flops per launch = (2 FMA + MUL + ADD + TRANS wave instructions) x 64 from profiles/%s_pmc_*_sq.txt; see tools/make_traffic_json.py" % rnd}
@@ -63,6 +81,7 @@ for mode in ("clear", "cloudy"):
         f = 64.0 * (2.0 * sq["SQ_INSTS_VALU_FMA_F64"][k] + sq["SQ_INSTS_VALU_MUL_F64"].get(k, 0) + sq["SQ_INSTS_VALU_ADD_F64"].get(k, 0) + sq["SQ_INSTS_VALU_TRANS_F64"].get(k, 0))
         if f > 1.0e6:
             flops["%s|8192|60|%s" % (k, mode)] = f
+traffic["source_hash"] = flops["source_hash"] = src_hash
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 json.dump(flops, open(os.path.join(ROOT, "profiles", "fp64_flops.json"), "w"), indent=1)
 print(json.dumps(traffic, indent=1)); print(json.dumps(flops, indent=1))
