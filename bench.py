@@ -74,17 +74,36 @@ def _cpu_worker(args):
     else:
         from oracle.port_driver import PortLW, PortSW   # C restatement
         sw, lw = PortSW(), PortLW()
-    t0 = _t.perf_counter()
-    for _ in range(reps):      # the reference keeps (ngpt, ncol, nlay) automatics on the stack: chunks of `ncol`
+    sw.fluxes(c, mcica=cloudy); lw.fluxes(c, mcica=cloudy)      # (first call: page faults of the work arrays)
+    t0, calls = _t.perf_counter(), 0
+    while True:      # the reference keeps (ngpt, ncol, nlay) automatics on the stack: chunks of `ncol`; `reps` = seconds of work
         sw.fluxes(c, mcica=cloudy)
         lw.fluxes(c, mcica=cloudy)
-    return _t.perf_counter() - t0
+        calls += 1
+        if _t.perf_counter() - t0 >= reps:
+            break
+    return _t.perf_counter() - t0, calls
+
+
+def _host_cores():
+    """Cores this process may use: the affinity mask, cut to the cgroup's CPU quota when there is one."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(np.ceil(int(quota) / int(period)))))
+    except Exception:
+        pass
+    return max(1, n)
 
 
 def cpu_baseline(nlay, cloudy):
-    """Reference (or port) on ALL host cores of this box (os.cpu_count() processes: the Fortran is serial and keeps
-    process-global state), a bounded sample of about 10-30 s of CPU work per process; the 16-process figure of the earlier
-    rounds' lines is measured beside it (`with_16_processes`)."""
+    """Reference (or port) on ALL host cores this process may use (one process per core: the Fortran is serial and keeps
+    process-global state), each process working for a fixed ~10 s on chunks of the same synthetic columns; the 16-process
+    figure of the earlier rounds' lines is measured beside it (`with_16_processes`)."""
     import multiprocessing as mp
     try:
         from oracle import ref_driver
@@ -93,24 +112,25 @@ def cpu_baseline(nlay, cloudy):
         kind = "port"
     per = 256 if not cloudy else 96
 
-    def run(cores, reps):
+    def run(cores, seconds):
         ctx = mp.get_context("spawn")
         with ctx.Pool(cores) as pool:
             t0 = time.perf_counter()
-            times = pool.map(_cpu_worker, [(kind, per, nlay, cloudy, 1000 + i, reps) for i in range(cores)])
+            got = pool.map(_cpu_worker, [(kind, per, nlay, cloudy, 1000 + i, seconds) for i in range(cores)], chunksize=1)
             wall = time.perf_counter() - t0
-        # the timed compute regions run concurrently on `cores` processes
-        return cores * per * reps / max(times), max(times), wall
-    all_cores = max(1, os.cpu_count() or 1)
-    reps = int((96 if not cloudy else 48) * 60 / nlay) or 1      # ~10-20 s of CPU work per process
+        # the timed regions run concurrently (every process works for `seconds`): columns done by all / the longest region
+        tmax = max(t for t, _ in got)
+        return sum(calls for _, calls in got) * per / tmax, tmax, wall, sum(calls for _, calls in got)
+    all_cores = _host_cores()
     try:
-        v, tmax, wall = run(all_cores, max(1, reps // 2) if all_cores > 16 else reps)
+        v, tmax, wall, calls = run(all_cores, 10.0)
         out = {"value": v, "unit": "columns/s", "cores": all_cores, "kind": kind,
-               "sample": "%d processes (os.cpu_count()) x %d calls x %d synthetic columns x %d levels, LW+SW %s; compute region max %.2f s (pool wall %.1f s); "
-                         "LW on synthetic k-tables" % (all_cores, max(1, reps // 2) if all_cores > 16 else reps, per, nlay, "McICA" if cloudy else "clear-sky", tmax, wall)}
+               "sample": "%d processes (every core this process may use; os.cpu_count() = %d) x ~10 s of LW+SW %s calls on chunks of %d synthetic columns x %d "
+                         "levels: %d calls, longest timed region %.2f s (pool wall %.1f s); LW on synthetic k-tables"
+                         % (all_cores, os.cpu_count() or 0, "McICA" if cloudy else "clear-sky", per, nlay, calls, tmax, wall)}
         if all_cores > 16:
-            v16, t16, w16 = run(16, reps)
-            out["with_16_processes"] = {"value": v16, "cores": 16, "sample": "16 processes x %d calls x %d columns; compute region max %.2f s" % (reps, per, t16)}
+            v16, t16, w16, c16 = run(16, 8.0)
+            out["with_16_processes"] = {"value": v16, "cores": 16, "sample": "16 processes x ~8 s: %d calls of %d columns, longest timed region %.2f s" % (c16, per, t16)}
         return out
     except Exception as e:  # pragma: no cover
         return {"value": None, "unit": "columns/s", "cores": 0, "kind": kind, "sample": "cpu baseline failed: %r" % (e,)}
