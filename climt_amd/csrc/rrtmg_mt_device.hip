@@ -9,7 +9,8 @@
 // recurrence from there:
 //   mt_seed_kernel    <<<1, 256>>>       the seed's initial window and the words behind it, x[0 .. kMtBase)
 //   mt_jump_kernel    <<<segments, 640>>> window of segment k = XOR over the terms t^i of its polynomial of x[1 + i ..]
-//   mt_stream_kernel  <<<segments, 256>>> the segment's tempered 32-bit draws, in stream order, to HBM
+//   mt_stream_kernel  <<<segments, 256>>> the segment's tempered 32-bit draws, in stream order, to HBM (per group of
+//                     sub-columns whose draws fit 1 GB: the buffer is bounded whatever the grid)
 //   mt_mask_kernel    <<<(sub-columns, tiles), 64>>>  draws -> cloud-mask bits, one thread per (column, sub-column), with the
 //                     reference's conversion to a real number and its overlap rules
 // Same bits as the sequential stream (GPU test against the host generator the reference masks were checked with).
@@ -119,9 +120,10 @@ __global__ void __launch_bounds__(kMtJumpThreads) mt_jump_kernel(const uint32_t 
 
 // the tempered draws of segment k = (run g, piece sidx): out[g * count + sidx * piece ..], `piece` of them (the run's last piece:
 // what is left of its `count`)
-__global__ void __launch_bounds__(kMtGenThreads) mt_stream_kernel(const uint32_t *windows, long count, long piece, int npiece, uint32_t *out) {
+// (launched per GROUP of sub-columns, see mt_mask_device: seg0 = first segment of the group, whose draws start at out[0])
+__global__ void __launch_bounds__(kMtGenThreads) mt_stream_kernel(const uint32_t *windows, long count, long piece, int npiece, int seg0, uint32_t *out) {
   __shared__ uint32_t st[kMtN];
-  const int tid = threadIdx.x, k = blockIdx.x, g = k / npiece, sidx = k % npiece;
+  const int tid = threadIdx.x, k = seg0 + blockIdx.x, g = blockIdx.x / npiece, sidx = blockIdx.x % npiece;   // (seg0 is a multiple of npiece)
   for (int i = tid; i < kMtN; i += kMtGenThreads) st[i] = windows[(long)k * kMtN + i];
   __syncthreads();
   const long begin = (long)sidx * piece;
@@ -142,12 +144,13 @@ __device__ __forceinline__ double mt_real(uint32_t y) {
 // The stream keeps a column's draws together (layer fastest), the threads of a wavefront are 64 columns: the tile's
 // 64 x per_col draws -- one contiguous run of the stream -- are read coalesced into LDS and each lane takes its column from
 // there (row stride per_col | 1: odd, so the lanes' words sit in different banks).
-__global__ void __launch_bounds__(64) mt_mask_kernel(int ncol, int nlay, int icld, const double *cldfr, const uint32_t *draws, uint64_t *mask, int nw) {
+// (launched per group of sub-columns: g0 = the group's first sub-column, whose draws start at draws[0])
+__global__ void __launch_bounds__(64) mt_mask_kernel(int ncol, int nlay, int icld, const double *cldfr, const uint32_t *draws, uint64_t *mask, int nw, int g0) {
   extern __shared__ uint32_t sh[];
-  const int lane = threadIdx.x, col0 = blockIdx.y * 64, col = col0 + lane, g = blockIdx.x;
+  const int lane = threadIdx.x, col0 = blockIdx.y * 64, col = col0 + lane, g = g0 + blockIdx.x;
   const int per_col = icld == 3 ? 1 : nlay, ld = per_col | 1;
   const int ncols_here = ncol - col0 < 64 ? ncol - col0 : 64;
-  const uint32_t *src = draws + ((long)g * ncol + col0) * per_col;
+  const uint32_t *src = draws + ((long)blockIdx.x * ncol + col0) * per_col;
   for (int i = lane; i < ncols_here * per_col; i += 64) sh[(i / per_col) * ld + i % per_col] = src[i];
   __syncthreads();
   if (col >= ncol) return;
@@ -197,7 +200,15 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
   uint32_t *win = (uint32_t *)ctx->buf(std::string(tag) + "win", (size_t)nseg * kMtN * 4);
   uint32_t *lists = (uint32_t *)ctx->buf(std::string(tag) + "lists", (size_t)nseg * kMtListMax * 4);
   int32_t *counts = (int32_t *)ctx->buf(std::string(tag) + "counts", (size_t)nseg * 4);
-  uint32_t *draws = (uint32_t *)ctx->buf(std::string(tag) + "draws", (size_t)nsub * count * 4);
+  // The draws leave the stream kernel through HBM and are read once by the mask kernel: nsub x count words -- 275 MB for the
+  // longwave at 8192 x 60, 4.4 GB at 131 072 x 60 -- if all sub-columns were generated before any mask is formed.  The
+  // sub-columns are therefore worked off in groups whose draws fit 1 GB (RRTMG_HIP_MT_DRAWS_MB; one group up to ~30 000 columns x 60
+  // layers: the launches of a small grid are not cut into pieces that no longer fill the GPU); the buffer is reused by every group.
+  size_t budget = (size_t)1 << 30;
+  if (const char *env = getenv("RRTMG_HIP_MT_DRAWS_MB")) { const long mb = atol(env); if (mb > 0) budget = (size_t)mb << 20; }   // (tests: many groups on a small grid)
+  int gsub = (int)(budget / ((size_t)count * 4));
+  gsub = gsub < 1 ? 1 : (gsub > nsub ? nsub : gsub);
+  uint32_t *draws = (uint32_t *)ctx->buf(std::string(tag) + "draws", (size_t)gsub * count * 4);
   if (!x || !win || !lists || !counts || !draws) return ctx->status;
   // the jump polynomials depend on where the segments start, not on the seed: uploaded when the grid shape changes
   uint64_t *key = ctx->mt_key[which];
@@ -217,8 +228,11 @@ int mt_mask_device(rrtmg_ctx *ctx, int which, int ncol, int nlay, int nsub, int 
   if (mask_lds > 64 * 1024 && !mask_lds_ok) return ctx->fail(RRTMG_ERR_HIP, "mt_mask_kernel: %zu bytes of dynamic LDS refused", mask_lds);
   hipLaunchKernelGGL(mt_seed_kernel, dim3(1), dim3(kMtGenThreads), 0, s, (uint32_t)seed, x);
   hipLaunchKernelGGL(mt_jump_kernel, dim3(nseg), dim3(kMtJumpThreads), (size_t)kMtJumpLds, s, x, lists, counts, win);
-  hipLaunchKernelGGL(mt_stream_kernel, dim3(nseg), dim3(kMtGenThreads), 0, s, win, count, piece, npiece, draws);
-  hipLaunchKernelGGL(mt_mask_kernel, dim3(nsub, (ncol + 63) / 64), dim3(64), mask_lds, s, ncol, nlay, icld, cldfr, draws, mask, nw);
+  for (int g0 = 0; g0 < nsub; g0 += gsub) {
+    const int ng = nsub - g0 < gsub ? nsub - g0 : gsub;
+    hipLaunchKernelGGL(mt_stream_kernel, dim3(ng * npiece), dim3(kMtGenThreads), 0, s, win, count, piece, npiece, g0 * npiece, draws);
+    hipLaunchKernelGGL(mt_mask_kernel, dim3(ng, (ncol + 63) / 64), dim3(64), mask_lds, s, ncol, nlay, icld, cldfr, draws, mask, nw, g0);
+  }
   RRTMG_HIP_CHECK(ctx, hipGetLastError());
   return RRTMG_OK;
 }

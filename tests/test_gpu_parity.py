@@ -533,6 +533,22 @@ def test_mersenne_twister_masks_by_jump_ahead_equal_the_sequential_stream(gpu_ct
         assert all(np.array_equal(lw[k][:, lo:hi], l[k]) for k in lw), (lo, hi)
 
 
+def test_mersenne_twister_draw_buffer_is_bounded_by_sub_column_groups(gpu_ctx, monkeypatch):
+    """The draws of the Mersenne-twister stream pass through a work buffer of at most RRTMG_HIP_MT_DRAWS_MB (default 1 GB): the
+    sub-columns are generated and turned into mask bits group by group.  Same masks whatever the group size -- one sub-column
+    per group, a few, all at once -- for all three overlap rules."""
+    from climt_amd.synthetic import make_columns
+    c = make_columns(700, 60, cloudy=True, seed=8)
+    for icld in (1, 2, 3):
+        monkeypatch.delenv("RRTMG_HIP_MT_DRAWS_MB", raising=False)
+        want = {w: gpu_ctx.mcica_mask(w, c["play"], c["cldfr"], icld, 4711, 1) for w in ("sw", "lw")}
+        for mb in ("1", "3"):        # 700 x 60 draws x 4 B = 0.16 MB per sub-column: groups of 6 and of 18
+            monkeypatch.setenv("RRTMG_HIP_MT_DRAWS_MB", mb)
+            for w in ("sw", "lw"):
+                assert np.array_equal(gpu_ctx.mcica_mask(w, c["play"], c["cldfr"], icld, 4711, 1), want[w]), (icld, mb, w)
+    monkeypatch.delenv("RRTMG_HIP_MT_DRAWS_MB", raising=False)
+
+
 def test_reference_compatible_entry_points(gpu_ctx):
     """The symbols climt's Cython shims bind, called exactly as _rrtmg_sw.pyx does (pointers to scalars)."""
     from helpers import CONSTANTS, CPDAIR
