@@ -904,6 +904,17 @@ RRTMG_HD double lw_planck_deriv(const LwTab &T, int ib, double tt) {
   return p[0] + frac * (p[1] - p[0]);
 }
 
+// the same in two halves: the two table entries are requested where the temperature is known, the interpolation is formed
+// where the value is needed -- with the layer's taumol between the two in lw_solve_thread, the gathers fly under it
+struct LwPlanckRaw { double p0, p1, frac; };
+RRTMG_HD LwPlanckRaw lw_planck_fetch(const LwTab &T, int ib, double tt) {
+  int ind = (int)(tt - 159.0);
+  if (ind < 1) ind = 1; else if (ind > 180) ind = 180;
+  const double *p = T.t + T.totplnk + 181 * ib + (ind - 1);
+  return LwPlanckRaw{p[0], p[1], tt - 159.0 - (double)ind};
+}
+RRTMG_HD double lw_planck_finish(const LwPlanckRaw &r) { return r.p0 + r.frac * (r.p1 - r.p0); }
+
 // Scratch rows per (layer, item): atrans and bbugas (+ atot, bbutot in cloudy layers) as computed by the downward sweep,
 // read back by the upward sweep.  (Keeping only the gas optical depth and re-forming the terms going up halves the slab
 // and was measured 14 % slower: DESIGN.md 5.)
@@ -1062,9 +1073,9 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
 #pragma unroll
   for (int g = 0; g < G; ++g) { radld[g] = 0.0; radclrd[g] = 0.0; plfrac_bot[g] = 0.0; iclddn[g] = 0; cldrad[g] = 0.0; clrrad[g] = 0.0; radmr[g] = 0.0; }
   if constexpr (CLD) sink.dn(L, 0.0, 0.0); else sink.dn_clear(L, 0.0);
-  double tz_up = d.tlev[(long)L * N + col];
+  double plev_up = lw_planck_finish(lw_planck_fetch(T, ib, d.tlev[(long)L * N + col]));   // Planck function at the interface above the layer
   RRTMG_PH_DECL
-  RRTMG_PH_MARK(0, tz_up)      // 0: setup before the sweep
+  RRTMG_PH_MARK(0, plev_up)      // 0: setup before the sweep
   for (int lev = L; lev >= 1; --lev) {
     const int l = lev - 1;
     const long i = (long)l * N + col;
@@ -1072,14 +1083,18 @@ RRTMG_HD void lw_solve_thread(const LwDev &d, const LwTab &T, int col, int ig0, 
     lw_load_layer(d, col, l, s);
     RRTMG_PH_MARK(1, s.fac00 + s.colh2o + (double)s.jp)      // 1: the layer's prep rows have arrived
     V<G> plfrac;
+    // the layer's aerosol / temperature rows and the two Planck-table entries of each temperature are REQUESTED here and used
+    // after taumol: the gathers fly under taumol's table rows (LDS) and arithmetic.  The interface value is carried down from
+    // the layer above (the same two entries, the same arithmetic as interpolating it again).
+    const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
+    const LwPlanckRaw q_lay = lw_planck_fetch(T, ib, d.tlay[i]), q_dn = lw_planck_fetch(T, ib, d.tlev[i]);
     const V<G> taug = lw_taug<BAND, G, LDSK>(T, s, lev <= laytrop, ig0, plfrac, kb);
     RRTMG_PH_MARK(2, taug[0] + taug[G - 1] + plfrac[0])      // 2: taumol (LDS row gathers + arithmetic)
-    const double taua = d.tauaer ? d.tauaer[((long)ib * L + l) * N + col] : 0.0;
-    const double tz_dn = d.tlev[i];
-    const double blay = lw_planck(T, ib, d.tlay[i]);
-    const double dplankup = lw_planck(T, ib, tz_up) - blay;
-    const double dplankdn = lw_planck(T, ib, tz_dn) - blay;
-    tz_up = tz_dn;
+    const double blay = lw_planck_finish(q_lay);
+    const double plev_dn = lw_planck_finish(q_dn);
+    const double dplankup = plev_up - blay;
+    const double dplankdn = plev_dn - blay;
+    plev_up = plev_dn;
     RRTMG_PH_MARK(3, blay + dplankup + dplankdn + taua)      // 3: aerosol / temperature rows and the three Planck interpolations
     // band-level cloud state of this layer (shared by the g-points)
     bool icldlyr = false, cld_band = false;
