@@ -314,7 +314,8 @@ def main():
         enq[0] = enq[1] = 0.0
         enq[2] = 0
         per, ksw, klw, brackets, synced = [], [], [], [], []
-        for _ in range(reps_of(steps, ncol, nlay, cld)):      # EXACTLY `steps` steps per bracket; brackets repeated to >= 1 s
+        covered = 0.0
+        while covered < a.min_seconds * 1.05 and len(brackets) < 1000 or not brackets:      # EXACTLY `steps` steps per bracket; brackets repeated until --min-seconds are covered
             _hip.synchronize()
             t0 = time.perf_counter()
             if serial or a.sync_every_step:
@@ -328,6 +329,7 @@ def main():
                 ctx.synchronize()
             _hip.synchronize()
             brackets.append((time.perf_counter() - t0) * 1e3 / steps)
+            covered += brackets[-1] * steps * 1e-3
         ms = float(np.median(brackets))
         # per-step latency, host enqueue time and the event-timed kernel durations: a bracket with a host synchronize after
         # every step (an enqueue behind a full queue would measure the GPU, not the host)
@@ -351,11 +353,6 @@ def main():
             slw.append(ctx.kernel_ms("lw", cloudy=cld))
         n_all = max(1, enq[2])
         return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0])
-
-    def reps_of(k, ncol, nlay, cld):
-        """Brackets of exactly k steps needed for >= --min-seconds of timed region."""
-        est = ncol * (nlay / 60.0) / (2.7e6 if cld else 5.4e6)
-        return int(max(1, min(1000, np.ceil(a.min_seconds * 1.1 / (k * est)))))
 
     def pick_steps(ncol, nlay, cld):
         """Steps per bracket: about 1.5 s worth (estimated from the large-grid rates of DESIGN.md 5); brackets repeat to --min-seconds."""
@@ -420,7 +417,10 @@ def main():
             a.gather = "none"
             comm = _NoComm(rank, world)
         comm_kind = comm.kind
-        sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist, unpack=not a.no_unpack)
+        # every rank brings N columns of its own (weak scaling): the blocks are tile-aligned whenever N is a whole number of tiles
+        sr = ShardedRadiation(ctx, comm, N * world, L, gather=a.gather, allocator=alloc, force=a.force_dist, unpack=not a.no_unpack,
+                              align=64 if N % 64 == 0 else 1)
+        assert sr.ncol == N, (sr.ncol, N)
         if a.serial:
             ctx.set_deferred(False)
         sr.set_inputs(columns(N, L, cloudy), already_local=True)
@@ -447,7 +447,10 @@ def main():
             step()
         fence()
         per, ksw, klw, brackets = [], [], [], []
-        for _ in range(reps_of(steps, N, L, cloudy)):      # EXACTLY `steps` steps per bracket (barrier + sync on both sides)
+        covered = 0.0
+        # EXACTLY `steps` steps per bracket (barrier + sync on both sides); repeated until --min-seconds are covered -- by the
+        # all-reduced bracket time, which every rank holds identically: all ranks stop after the same bracket
+        while covered < a.min_seconds * 1.05 and len(brackets) < 1000 or not brackets:
             fence()
             t0 = time.perf_counter()
             for _ in range(steps):      # as at N=1: no host synchronize between the steps of a bracket (unless asked for)
@@ -456,6 +459,7 @@ def main():
             t = torch.tensor([(time.perf_counter() - t0) * 1e3 / steps], dtype=torch.float64, device="cuda:%d" % local)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)      # the slowest rank's bracket
             brackets.append(float(t.item()))
+            covered += brackets[-1] * steps * 1e-3
         ms = float(np.median(brackets))
         fence()
         for _ in range(min(steps, 200)):      # per-step latency and kernel durations: synchronized steps, outside the brackets
@@ -470,7 +474,7 @@ def main():
         if sr.do_gather:
             had, sr.do_gather = True, False
             nb = []
-            for _ in range(max(1, reps_of(steps, N, L, cloudy) // 2)):
+            for _ in range(max(1, len(brackets) // 2)):
                 fence()
                 t0 = time.perf_counter()
                 for _ in range(steps):
