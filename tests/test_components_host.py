@@ -321,6 +321,50 @@ def test_3d_caches_from_generated_default_state(cls):
     check_3d_cache_from_generated_state(cls)
 
 
+def _reorder_state(state, pattern):
+    """The reference's test_reversed_state_gives_same_output (tests/test_components.py:291-308: every 3-d quantity transposed to
+    (dims[2], dims[1], dims[0]), every 2-d one to (dims[1], dims[0])) and test_transposed_state_gives_same_output (:310-327:
+    (dims[2], dims[0], dims[1])) -- the VERTICAL axis moves too."""
+    out = {}
+    for name, v in state.items():
+        if not hasattr(v, "dims"):
+            out[name] = v
+            continue
+        nd = len(v.dims)
+        if nd == 3:
+            order = (2, 1, 0) if pattern == "reversed" else (2, 0, 1)
+        elif nd == 2:
+            order = (1, 0)
+        else:
+            out[name] = v
+            continue
+        out[name] = sc.DataArray(np.ascontiguousarray(np.transpose(v.values, order)), dims=[v.dims[i] for i in order], attrs=v.attrs)
+    return out
+
+
+@pytest.mark.parametrize("pattern", ["reversed", "transposed"])
+def test_reversed_and_transposed_states_give_the_cached_output(pattern):
+    """tests/test_components.py:291-327 for the two radiation classes on the reference's 32 x 16 x 28 default state: the
+    shortwave against the reference's 3-d cache (1e-8, its criterion), the longwave (synthetic tables: no cache to meet) against
+    its own output on the untouched state, bit for bit -- columns are independent and the extraction only re-labels axes."""
+    for cls, comp in (("TestRRTMGShortwave", climt_amd.RRTMGShortwave()), ("TestRRTMGLongwave", climt_amd.RRTMGLongwave(allow_synthetic_tables=True))):
+        nx, ny = (32, 16) if cls == "TestRRTMGShortwave" else (6, 4)          # (the cache is 32 x 16; the emulation is slow)
+        state = climt_amd.get_default_state([comp], grid_state=climt_amd.get_grid(nx=nx, ny=ny, nz=28))
+        t0, d0 = comp(state)
+        t1, d1 = comp(_reorder_state(state, pattern))
+        for a, b in ((t0, t1), (d0, d1)):
+            for k in a:
+                bb = np.transpose(b[k].values, [b[k].dims.index(x) for x in a[k].dims])
+                assert np.array_equal(a[k].values, bb), (cls, pattern, k)
+        if cls == "TestRRTMGShortwave":
+            exp = _cacheout(cls)
+            for got, want in ((t1, exp["tend"]), (d1, exp["diag"])):
+                for k, w in want.items():
+                    dims = tuple(x for x in str(w["dims"]).split(",") if x)
+                    g = np.transpose(got[k].values, [got[k].dims.index(x) for x in dims])
+                    assert maxdiff(g, w["values"]) <= 1e-8, (pattern, k)
+
+
 def test_output_pool_never_hands_out_an_array_somebody_still_holds():
     """climt_amd.rrtmg.common.OutputPool: the radiation components write into the arrays of an EARLIER call only when the
     caller has dropped every reference to them (DataArray, raw array, any view) -- the reference allocates afresh each call,

@@ -1111,6 +1111,31 @@ def test_3d_reference_caches_from_generated_default_state(cls):
     check_3d_cache_from_generated_state(cls)
 
 
+@pytest.mark.parametrize("pattern", ["reversed", "transposed"])
+def test_reversed_and_transposed_states_give_the_cached_output_on_the_gpu(pattern):
+    """tests/test_components.py:291-327 through the library: every quantity of the reference's 32 x 16 x 28 default state with its
+    axes re-ordered (the vertical one too) -- the shortwave meets the reference's 3-d cache at 1e-8, both spectra return the
+    bits of the untouched state (the re-ordered arrays take the host-conversion route of the extraction, the untouched ones the
+    device-conversion route: the two must agree)."""
+    import climt_amd
+    from test_components_host import _cacheout, _reorder_state
+    for cls, comp in (("TestRRTMGShortwave", climt_amd.RRTMGShortwave()), ("TestRRTMGLongwave", climt_amd.RRTMGLongwave(allow_synthetic_tables=True))):
+        state = climt_amd.get_default_state([comp], grid_state=climt_amd.get_grid(nx=32, ny=16, nz=28))
+        t0, d0 = comp(state)
+        t1, d1 = comp(_reorder_state(state, pattern))
+        for a, b in ((t0, t1), (d0, d1)):
+            for k in a:
+                bb = np.transpose(b[k].values, [b[k].dims.index(x) for x in a[k].dims])
+                assert np.array_equal(a[k].values, bb), (cls, pattern, k)
+        if cls == "TestRRTMGShortwave":
+            exp = _cacheout(cls)
+            for got, want in ((t1, exp["tend"]), (d1, exp["diag"])):
+                for k, w in want.items():
+                    dims = tuple(x for x in str(w["dims"]).split(",") if x)
+                    g = np.transpose(got[k].values, [got[k].dims.index(x) for x in dims])
+                    assert maxdiff(g, w["values"]) <= 1e-8, (pattern, k)
+
+
 @pytest.mark.parametrize("mode", ["all", "root", "none"])
 def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
     """climt_amd.distributed.ShardedRadiation on the device with RcclComm (librccl bound through ctypes, its own stream,
