@@ -54,8 +54,11 @@ def main():
         if lw_in["iceflg"] == 0:
             lw_in["reice"] = np.maximum(lw_in["reice"], 10.0)
         gsw, glw = ctx.sw_fluxes(sw_in, mcica=mcica), ctx.lw_fluxes(lw_in, mcica=mcica)
-        rsw, _, kind = live_oracle(sw_in, mcica, chunk=128, procs=8, spectra=("sw",), timeout=300)
-        _, rlw, _ = live_oracle(lw_in, mcica, chunk=128, procs=8, spectra=("lw",), timeout=300)
+        # the Mersenne twister's stream runs over (sub-column, column, layer) of the WHOLE call: the reference cannot be fed in
+        # column chunks then (kissvec seeds per column, clear sky draws nothing)
+        chunk = ncol if (mcica and c["irng"] == 1) else 128
+        rsw, _, kind = live_oracle(sw_in, mcica, chunk=chunk, procs=8, spectra=("sw",), timeout=300)
+        _, rlw, _ = live_oracle(lw_in, mcica, chunk=chunk, procs=8, spectra=("lw",), timeout=300)
         dsw = max(maxdiff(gsw[k], rsw[k]) for k in rsw); dlw = max(maxdiff(glw[k], rlw[k]) for k in rlw)
         worst["sw"], worst["lw"] = max(worst["sw"], dsw), max(worst["lw"], dlw)
         flag = "" if dsw < 1e-6 and dlw < 1e-7 else "   <<<<<<"
