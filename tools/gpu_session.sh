@@ -33,14 +33,17 @@ for sec in "$@"; do
       done
       timeout 600 python bench.py --columns 131072 --no-cpu-baseline --no-extra > $O/${R}_bench_clear131072.log 2>&1; grep "^{" $O/${R}_bench_clear131072.log | tail -1 > $O/${R}_bench_clear131072.json; cut -c1-300 $O/${R}_bench_clear131072.json ;;
     ab:*)
-      for lib in $(echo ${sec#ab:} | tr , ' '); do
-        for mode in "" "--cloudy"; do
-          L=$PWD/climt_amd/_lib/$lib; [ $lib = product ] && L=$PWD/climt_amd/_lib/librrtmg_hip.so
-          RRTMG_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 150 $mode 2>&1 | tail -1 | python -c "
+      # entries: <lib>[+ENV=VALUE[+ENV=VALUE...]]; AB_MODES="clear" | "cloudy" | "clear cloudy" (default both)
+      for ent in $(echo ${sec#ab:} | tr , ' '); do
+        lib=${ent%%+*}; envs=""; [ "$ent" != "$lib" ] && envs=$(echo ${ent#*+} | tr + ' ')
+        for m in ${AB_MODES:-clear cloudy}; do
+          mode=""; [ $m = cloudy ] && mode="--cloudy"
+          L=$PWD/climt_amd/_lib/ab/$lib; [ $lib = product ] && L=$PWD/climt_amd/_lib/librrtmg_hip.so
+          env $envs RRTMG_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 150 $mode 2>&1 | tail -1 | python -c "
 import json,sys
 try:
     j=json.loads(sys.stdin.read()); r=j['roofline']
-    print('%-14s %-8s %9d col/s %7.3f ms (median %.3f)  sw %.3f lw %.3f | serial sw %.3f lw %.3f' % ('$lib', '$mode', j['value'], j['ms_per_step'], j['config']['ms_per_step_median'], r['sw_solve_ms'], r['lw_solve_ms'], r['sw_solve_ms_serial'], r['lw_solve_ms_serial']))
+    print('%-40s %-8s %9d col/s %7.3f ms (median %.3f)  sw %.3f lw %.3f | serial sw %.3f lw %.3f' % ('$ent', '$mode', j['value'], j['ms_per_step'], j['config']['ms_per_step_median'], r['sw_solve_ms'], r['lw_solve_ms'], r['sw_solve_ms_serial'], r['lw_solve_ms_serial']))
 except Exception as e:
     print('$lib $mode FAILED', e)" | tee -a $O/${R}_ab.txt
         done
