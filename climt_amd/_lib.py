@@ -31,7 +31,7 @@ _SCALES = ("pressure_scale", "water_path_scale", "h2o_mul", "h2o_div")
 
 class SwArgs(C.Structure):
     _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld iaer inflgsw iceflgsw liqflgsw dyofyr isolvar "
-                                     "irng permuteseed shard_col0 shard_ncol reserved0").split()]
+                                     "irng permuteseed shard_col0 shard_ncol struct_size").split()]
                 + [(n, _f64) for n in "adjes scon solcycfrac".split()]
                 + [(n, _vp) for n in ("bndsolvar indsolvar play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr "
                                       "asdir asdif aldir aldif coszen cldfr taucld ssacld asmcld fsfcld cicewp cliqwp reice "
@@ -41,7 +41,7 @@ class SwArgs(C.Structure):
 
 class LwArgs(C.Structure):
     _fields_ = ([(n, _i32) for n in ("ncol nlay memspace mcica icld idrv inflglw iceflglw liqflglw irng permuteseed "
-                                     "shard_col0 shard_ncol reserved0").split()]
+                                     "shard_col0 shard_ncol struct_size").split()]
                 + [(n, _vp) for n in ("play plev tlay tlev tsfc h2ovmr o3vmr co2vmr ch4vmr n2ovmr o2vmr cfc11vmr cfc12vmr "
                                       "cfc22vmr ccl4vmr emis cldfr taucld cicewp cliqwp reice reliq tauaer cldfmcl "
                                       "uflx dflx hr uflxc dflxc hrc duflx_dt duflxc_dt").split()]
@@ -339,6 +339,7 @@ class Context:
     def sw_fluxes(self, inp, mcica=False, out=None, memspace=0):
         nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
         a = SwArgs()
+        a.struct_size = C.sizeof(SwArgs)
         keep = []
         a.ncol, a.nlay, a.memspace, a.mcica = int(ncol), int(nlay), int(memspace), int(bool(mcica))
         a.icld, a.inflgsw, a.iceflgsw, a.liqflgsw, a.dyofyr = 1, 2, 1, 1, 1
@@ -356,6 +357,7 @@ class Context:
     def lw_fluxes(self, inp, mcica=False, out=None, memspace=0):
         nlay, ncol = (inp["nlay"], inp["ncol"]) if memspace else inp["play"].shape
         a = LwArgs()
+        a.struct_size = C.sizeof(LwArgs)
         keep = []
         a.ncol, a.nlay, a.memspace, a.mcica = int(ncol), int(nlay), int(memspace), int(bool(mcica))
         a.icld, a.inflglw, a.iceflglw, a.liqflglw = 1, 2, 1, 1

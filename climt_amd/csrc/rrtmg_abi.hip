@@ -8,6 +8,8 @@
 #include <condition_variable>
 #include <memory>
 
+#include <cstddef>
+
 #include "rrtmg_ctx.h"
 
 namespace rrtmg {
@@ -22,10 +24,24 @@ const char *status_message(int code) {
     case RRTMG_ERR_PARTIAL_CLOUD: return "PARTIAL CLOUD NOT ALLOWED";
     case RRTMG_ERR_ICE_RADIUS: return "ICE RADIUS OUT OF BOUNDS";
     case RRTMG_ERR_LIQ_RADIUS: return "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS";
-    case RRTMG_ERR_CLOUD_OPTICS: return "CLOUD OPTICAL PROPERTY OUT OF RANGE";
     case RRTMG_ERR_KISS_PRESSURE: return "MCICA_SUBCOL: KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS.";
     case RRTMG_ERR_ICLD: return "MCICA_SUBCOL: INVALID ICLD";
-    case RRTMG_ERR_UNSUPPORTED: return "option not supported by this build";
+    case RRTMG_ERR_INFLAG1_MCICA: return "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA";
+    case RRTMG_ERR_ICE_GEN_SIZE: return "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS";
+    case RRTMG_ERR_ICE_RADIUS_SMALL: return "ICE RADIUS TOO SMALL";
+    case RRTMG_ERR_UNSUPPORTED: return "option not supported by RRTMG";
+    case RRTMG_ERR_ICE_EXT_NEG: return "ICE EXTINCTION LESS THAN 0.0";
+    case RRTMG_ERR_ICE_SSA_GT1: return "ICE SSA GRTR THAN 1.0";
+    case RRTMG_ERR_ICE_SSA_NEG: return "ICE SSA LESS THAN 0.0";
+    case RRTMG_ERR_ICE_ASYM_GT1: return "ICE ASYM GRTR THAN 1.0";
+    case RRTMG_ERR_ICE_ASYM_NEG: return "ICE ASYM LESS THAN 0.0";
+    case RRTMG_ERR_FDELTA_NEG: return "FDELTA LESS THAN 0.0";
+    case RRTMG_ERR_FDELTA_GT1: return "FDELTA GT THAN 1.0";
+    case RRTMG_ERR_LIQ_EXT_NEG: return "LIQUID EXTINCTION LESS THAN 0.0";
+    case RRTMG_ERR_LIQ_SSA_GT1: return "LIQUID SSA GRTR THAN 1.0";
+    case RRTMG_ERR_LIQ_SSA_NEG: return "LIQUID SSA LESS THAN 0.0";
+    case RRTMG_ERR_LIQ_ASYM_GT1: return "LIQUID ASYM GRTR THAN 1.0";
+    case RRTMG_ERR_LIQ_ASYM_NEG: return "LIQUID ASYM LESS THAN 0.0";
     default: return "unknown error";
   }
 }
@@ -252,6 +268,24 @@ std::string default_blob_path(const char *which) {
 
 using namespace rrtmg;
 
+// The caller's struct is copied into one of the library's own: struct_size 0 = the round-3 layout that ended with the
+// outputs (nothing behind them is read: the unit factors stay zero), sizeof = this header; anything else was built against
+// another header and is refused.  Unit factors are for host arrays only.
+template <class Args, class Impl>
+static int checked_call(rrtmg_ctx *ctx, const Args *a, size_t old_size, const char *what, Impl impl) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  if (!a) return ctx->fail(RRTMG_ERR_ARG, "%s: NULL argument struct", what);
+  if (a->struct_size != 0 && (size_t)a->struct_size != sizeof(Args))
+    return ctx->fail(RRTMG_ERR_ARG, "%s: struct_size %d is not sizeof(%s_args) = %zu of this library (ABI version %d): rebuild the caller against include/rrtmg_hip.h",
+                     what, (int)a->struct_size, what, sizeof(Args), RRTMG_HIP_ABI_VERSION);
+  Args own{};
+  memcpy(&own, a, a->struct_size ? sizeof(Args) : old_size);
+  own.struct_size = (int32_t)sizeof(Args);
+  if (own.memspace == 1 && (own.pressure_scale != 0.0 || own.water_path_scale != 0.0 || own.h2o_mul != 0.0 || own.h2o_div != 0.0))
+    return ctx->fail(RRTMG_ERR_ARG, "%s: unit factors (pressure_scale, water_path_scale, h2o_mul, h2o_div) apply to host arrays only (memspace 0)", what);
+  return impl(ctx, &own);
+}
+
 extern "C" {
 
 #ifndef RRTMG_SRC_HASH
@@ -380,8 +414,9 @@ long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long cap
   return n;
 }
 
-int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a) { return ctx ? sw_fluxes_impl(ctx, a) : RRTMG_ERR_ARG; }
-int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a) { return ctx ? lw_fluxes_impl(ctx, a) : RRTMG_ERR_ARG; }
+int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a) { return checked_call(ctx, a, offsetof(rrtmg_sw_args, pressure_scale), "rrtmg_sw", sw_fluxes_impl); }
+int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a) { return checked_call(ctx, a, offsetof(rrtmg_lw_args, pressure_scale), "rrtmg_lw", lw_fluxes_impl); }
+int rrtmg_hip_abi_version(void) { return RRTMG_HIP_ABI_VERSION; }
 
 int rrtmg_hip_mcica_mask(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,
                          const double *play, const double *cldfrac, double *cldfmcl) {

@@ -4,6 +4,7 @@
 
 #include <cstdint>
 
+#include "../../include/rrtmg_hip.h"   // the status codes (RRTMG_ERR_*)
 #include "rrtmg_profile.h"
 
 // One code path: the experiments of rounds 1-3 (ablations, occupancy and launch-shape variants, alternative layouts) were

@@ -208,7 +208,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   RRTMG_PROFILE_READ_ONLY_ITEM(d)
   d.fluxfac = (2.0 * asin(1.0)) * 2.e4;       // rrtmg_lw_rad.nomcica.f90:420-421
   const bool maxrand = !d.mcica && d.icld >= 2;   // rtrnmr (rrtmg_lw_rad.nomcica.f90:527-544)
-  if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA");
+  if (d.mcica && d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_INFLAG1_MCICA, "longwave: %s", status_message(RRTMG_ERR_INFLAG1_MCICA));   // rrtmg_lw_cldprmc.f90:172
 
   // ---- inputs (rrtmg_host_inputs.h: uniform arrays are filled on the device, all-zero band arrays are absent) ----------------
   bool ok = true;

@@ -243,6 +243,9 @@ RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
   const double cldmin = 1.e-20;
   const int icb1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
   int ncbands = 1;
+  // first failed check in program order (see sw_cloud_layer); one code per distinct `stop` message of rrtmg_lw_cldprop.f90
+  int e = 0;
+  auto chk = [&](bool bad, int code) { if (e == 0 && bad) e = code; };
   for (int l = 0; l < L; ++l) {
     const long i = (long)l * N + col;
     for (int ib = 0; ib < 16; ++ib) d.ctau[((long)ib * L + l) * N + col] = 0.0;
@@ -265,18 +268,18 @@ RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
       if (ciwp == 0.0) {
         abscoice[0] = 0.0; iceind = 0;
       } else if (d.iceflag == 0) {
-        if (radice < 10.0) report_error(d.err, 11);
+        chk(radice < 10.0, RRTMG_ERR_ICE_RADIUS_SMALL);   // rrtmg_lw_cldprop.f90:193
         abscoice[0] = t[T.absice0] + t[T.absice0 + 1] / radice;
         iceind = 0;
       } else if (d.iceflag == 1) {
-        if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+        chk(radice < 13.0 || radice > 130., RRTMG_ERR_ICE_RADIUS);   // :198
         ncbands = 5;
         for (int ib = 0; ib < 5; ++ib) abscoice[ib] = t[T.absice1 + 2 * ib] + t[T.absice1 + 2 * ib + 1] / radice;
         iceind = 1;
       } else if (d.iceflag == 2) {
-        if (radice < 5.0 || radice > 131.0) report_error(d.err, 11);
+        chk(radice < 5.0 || radice > 131.0, RRTMG_ERR_ICE_RADIUS);   // :209
         ncbands = 16;
-        const double factor = (radice - 2.0) / 3.0;
+        const double factor = e ? 1.0 : (radice - 2.0) / 3.0;
         int index = (int)factor;
         if (index == 43) index = 42;
         if (index < 1) index = 1;
@@ -287,9 +290,9 @@ RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
         }
         iceind = 2;
       } else if (d.iceflag == 3) {
-        if (radice < 5.0 || radice > 140.0) report_error(d.err, 11);
+        chk(radice < 5.0 || radice > 140.0, RRTMG_ERR_ICE_GEN_SIZE);   // :225
         ncbands = 16;
-        const double factor = (radice - 2.0) / 3.0;
+        const double factor = e ? 1.0 : (radice - 2.0) / 3.0;
         int index = (int)factor;
         if (index == 46) index = 45;
         if (index < 1) index = 1;
@@ -308,7 +311,7 @@ RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
         if (iceind == 1) iceind = 2;
       } else if (d.liqflag == 1) {
         const double radliq = d.reliq[i];
-        if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+        chk(radliq < 2.5 || radliq > 60., RRTMG_ERR_LIQ_RADIUS);   // :253
         int index = (int)(radliq - 1.5);
         if (index == 0) index = 1;
         if (index == 58) index = 57;
@@ -325,11 +328,14 @@ RRTMG_HD void lw_cloud_column(const LwDev &d, const LwTab &T, int col) {
       for (int ib = 0; ib < ncbands; ++ib) {
         const int ii = iceind == 0 ? 0 : (iceind == 1 ? icb1[ib] - 1 : ib);
         const int il = liqind == 0 ? 0 : ib;
-        d.ctau[((long)ib * L + l) * N + col] = ciwp * abscoice[ii] + clwp * abscoliq[il];
+        // (behind a failed check: no cloud optical depth -- the solve kernels run to the end of the call whatever the flag
+        // says, and an extrapolated, negative optical depth would take their table lookups out of bounds)
+        d.ctau[((long)ib * L + l) * N + col] = e ? 0.0 : ciwp * abscoice[ii] + clwp * abscoliq[il];
       }
     }
   }
   d.ncbands[col] = ncbands;
+  if (e) report_error(d.err, e);
 }
 
 // cldprmc band values for one (column, layer): every cloudy sub-column of band ib gets this tau
@@ -342,7 +348,9 @@ RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay)
   const int icb1[16] = {1, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5, 5, 5, 5, 5, 5};
   const double ciwp = d.cicewp ? d.cicewp[i] : 0.0, clwp = d.cliqwp ? d.cliqwp[i] : 0.0;
   const double cwp = ciwp + clwp;
-  if (d.inflag == 1) report_error(d.err, 20);
+  int e = 0;
+  auto chk = [&](bool bad, int code) { if (e == 0 && bad) e = code; };
+  chk(d.inflag == 1, RRTMG_ERR_INFLAG1_MCICA);   // rrtmg_lw_cldprmc.f90:172
   for (int ib = 0; ib < 16; ++ib) {
     const double tin = d.taucld ? d.taucld[i * 16 + ib] : 0.0;
     double tau = tin;
@@ -352,16 +360,17 @@ RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay)
       const double radice = d.reice[i];
       if (ciwp == 0.0) {
       } else if (d.iceflag == 0) {
-        if (radice < 10.0) report_error(d.err, 11);
+        chk(radice < 10.0, RRTMG_ERR_ICE_RADIUS_SMALL);   // :185
         abscoice = t[T.absice0] + t[T.absice0 + 1] / radice;
       } else if (d.iceflag == 1) {
-        if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+        chk(radice < 13.0 || radice > 130., RRTMG_ERR_ICE_RADIUS);   // :189
         const int jb = icb1[ib] - 1;
         abscoice = t[T.absice1 + 2 * jb] + t[T.absice1 + 2 * jb + 1] / radice;
       } else if (d.iceflag == 2 || d.iceflag == 3) {
         const int nr = d.iceflag == 2 ? 43 : 46;
-        if (radice < 5.0 || radice > (d.iceflag == 2 ? 131.0 : 140.0)) report_error(d.err, 11);
-        const double factor = (radice - 2.0) / 3.0;
+        if (d.iceflag == 2) chk(radice < 5.0 || radice > 131.0, RRTMG_ERR_ICE_RADIUS);   // :198
+        else chk(radice < 5.0 || radice > 140.0, RRTMG_ERR_ICE_GEN_SIZE);                // :212
+        const double factor = e ? 1.0 : (radice - 2.0) / 3.0;
         int index = (int)factor;
         if (index == nr) index = nr - 1;
         if (index < 1) index = 1;
@@ -374,7 +383,7 @@ RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay)
         abscoliq = t[T.absliq0];
       } else if (d.liqflag == 1) {
         const double radliq = d.reliq[i];
-        if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+        chk(radliq < 2.5 || radliq > 60., RRTMG_ERR_LIQ_RADIUS);   // :234
         int index = (int)(radliq - 1.5);
         if (index == 0) index = 1;
         if (index == 58) index = 57;
@@ -384,10 +393,11 @@ RRTMG_HD void lw_cloudmc_layer(const LwDev &d, const LwTab &T, int col, int lay)
         const long k = T.absliq1 + (index - 1) + 58 * ib;
         abscoliq = t[k] + fint * (t[k + 1] - (t[k]));
       }
-      tau = ciwp * abscoice + clwp * abscoliq;
+      tau = e ? 0.0 : ciwp * abscoice + clwp * abscoliq;   // (see lw_cloud_column)
     }
     d.ctau[((long)ib * L + lay) * N + col] = tau;
   }
+  if (e) report_error(d.err, e);
 }
 
 // OR of the sub-column masks: icldlyr of rtrnmc (rrtmg_lw_rtrnmc.f90:298-312)
@@ -950,7 +960,10 @@ RRTMG_HD LwPartSink lw_part_sink(const LwDev &d, int slot, int col) {
 
 // quotient of the Pade table index x/(bpade + x): the IEEE division (the index decides which table entry is read)
 #define LW_TDIV(a, b) ((a) / (b))
-#define LW_TBLIDX(x) ((int)(x))
+// (clamped to the table, 0 .. ntbl: these are per-lane GLOBAL gathers, and an optical depth that is negative or not a number
+//  -- input the reference would index out of bounds with -- must not take them out of the allocation; one v_med3_i32)
+RRTMG_HD int lw_tblidx(double x) { const int i = (int)x; return i < 0 ? 0 : (i > 10000 ? 10000 : i); }
+#define LW_TBLIDX(x) lw_tblidx(x)
 // Transmittance and Planck source terms of ONE (layer, g-point) cell from its gas optical depth (already times the
 // diffusivity angle, clamped at zero) -- rrtmg_lw_rtrn.f90:342-447 / rrtmg_lw_rtrnmc.f90:342-456.  Called by the downward
 // sweep only; the upward sweep reads the terms back from the scratch rows (LF_*).

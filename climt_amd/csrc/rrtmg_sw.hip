@@ -295,6 +295,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
                          omg >= 0 ? ctx->sw_ts.flat.data() + omg : nullptr, osb >= 0 ? ctx->sw_ts.flat.data() + osb : nullptr, svar_col, err);
   }
   if (rc) return ctx->fail(rc, "%s", err.c_str());
+  if (d.icld >= 1 && d.inflag == 1 && d.mcica) return ctx->fail(RRTMG_ERR_INFLAG1_MCICA, "shortwave: %s", status_message(RRTMG_ERR_INFLAG1_MCICA));   // rrtmg_sw_cldprmc.f90:166
   if (d.icld >= 1 && d.inflag == 1) return ctx->fail(RRTMG_ERR_UNSUPPORTED, "inflgsw=1 has no shortwave implementation in RRTMG_SW (cldprop_sw handles 0 and 2)");
 
   // ---- inputs (rrtmg_host_inputs.h: uniform arrays are filled on the device, all-zero band arrays are absent) ----------------

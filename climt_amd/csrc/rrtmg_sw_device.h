@@ -193,7 +193,7 @@ RRTMG_HD int sw_prep_layer(const SwDev &d, const SwTab &T, int col, int l) {
     if (d.icld >= 1 && d.cldfr) {
       const double cf = d.cldfr[i];
       // rrtmg_sw_rad.nomcica.f90:616-620
-      if (!d.mcica && cf > 1.e-6 && cf < 1.0 - 1.e-6) report_error(d.err, 10);
+      if (!d.mcica && cf > 1.e-6 && cf < 1.0 - 1.e-6) report_error(d.err, RRTMG_ERR_PARTIAL_CLOUD);
     }
     return packed;
   }
@@ -273,6 +273,11 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
   }
   // McICA gate is per sub-column (cldfmc >= cldmin and (cwp >= cldmin or taucmc >= cldmin)) with the
   // band's tauc; nomcica gate uses the band-summed tauctot.
+  // The reference stops at the FIRST failed check in program order (layer, then g-point / band, then the order of the
+  // source lines); a thread keeps the first code it meets (`chk`) and skips the arithmetic behind it, across threads the
+  // largest code wins (report_error).  One code per distinct `stop` message: include/rrtmg_hip.h.
+  int e = 0;
+  auto chk = [&](bool bad, int code) { if (e == 0 && bad) e = code; };
   for (int b = 0; b < kSwNBand; ++b) {
     const long o = ((long)b * L + lay) * N + col;
     double tau = 0.0, ssa = 1.0, asy = 0.0;
@@ -294,7 +299,7 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
         const double radice = d.reice[i];
         if (ciwp == 0.0) {
         } else if (d.iceflag == 1) {
-          if (radice < 13.0 || radice > 130.) report_error(d.err, 11);
+          chk(radice < 13.0 || radice > 130., RRTMG_ERR_ICE_RADIUS);   // rrtmg_sw_cldprop.f90:194, cldprmc:183
           const double wn2 = t[T.wavenum2 + b];
           int icx = 5;
           if (wn2 > 1.43e04) icx = 1; else if (wn2 > 7.7e03) icx = 2; else if (wn2 > 5.3e03) icx = 3; else if (wn2 > 4.0e03) icx = 4;
@@ -304,8 +309,8 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
           if (gice >= 1.0) gice = 1.0 - eps;
           forwice = gice * gice;
         } else if (d.iceflag == 2) {
-          if (radice < 5.0 || radice > 131.0) report_error(d.err, 11);
-          const double factor = (radice - 2.0) / 3.0;
+          chk(radice < 5.0 || radice > 131.0, RRTMG_ERR_ICE_RADIUS);   // :226 / :213
+          const double factor = e ? 1.0 : (radice - 2.0) / 3.0;
           int index = (int)factor;
           if (index == 43) index = 42;
           if (index < 1) index = 1;
@@ -316,8 +321,8 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
           gice = t[T.asyice2 + k] + fint * (t[T.asyice2 + k + 1] - t[T.asyice2 + k]);
           forwice = gice * gice;
         } else if (d.iceflag == 3) {
-          if (radice < 5.0 || radice > 140.0) report_error(d.err, 11);
-          const double factor = (radice - 2.0) / 3.0;
+          chk(radice < 5.0 || radice > 140.0, RRTMG_ERR_ICE_GEN_SIZE);   // :250 / :236
+          const double factor = e ? 1.0 : (radice - 2.0) / 3.0;
           int index = (int)factor;
           if (index == 46) index = 45;
           if (index < 1) index = 1;
@@ -327,18 +332,20 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
           ssacoice = t[T.ssaice3 + k] + fint * (t[T.ssaice3 + k + 1] - t[T.ssaice3 + k]);
           gice = t[T.asyice3 + k] + fint * (t[T.asyice3 + k + 1] - t[T.asyice3 + k]);
           const double fdelta = t[T.fdlice3 + k] + fint * (t[T.fdlice3 + k + 1] - t[T.fdlice3 + k]);
-          if (fdelta < 0.0 || fdelta > 1.0) report_error(d.err, 13);
+          chk(fdelta < 0.0, RRTMG_ERR_FDELTA_NEG); chk(fdelta > 1.0, RRTMG_ERR_FDELTA_GT1);   // :264-265 / :250-251
           forwice = fdelta + 0.5 / ssacoice;
           if (forwice > gice) forwice = gice;
         } else {
-          report_error(d.err, 20);
+          chk(true, RRTMG_ERR_UNSUPPORTED);
         }
-        if (ciwp != 0.0 && (extcoice < 0.0 || ssacoice > 1.0 || ssacoice < 0.0 || gice > 1.0 || gice < 0.0))
-          report_error(d.err, 13);
+        if (ciwp != 0.0) {   // :216-220, :240-244, :270-274 / cldprmc :204-208, :227-231, :256-260 (after each parameterisation)
+          chk(extcoice < 0.0, RRTMG_ERR_ICE_EXT_NEG); chk(ssacoice > 1.0, RRTMG_ERR_ICE_SSA_GT1); chk(ssacoice < 0.0, RRTMG_ERR_ICE_SSA_NEG);
+          chk(gice > 1.0, RRTMG_ERR_ICE_ASYM_GT1); chk(gice < 0.0, RRTMG_ERR_ICE_ASYM_NEG);
+        }
         if (clwp == 0.0) {
         } else if (d.liqflag == 1) {
           const double radliq = d.reliq[i];
-          if (radliq < 2.5 || radliq > 60.) report_error(d.err, 12);
+          chk(radliq < 2.5 || radliq > 60., RRTMG_ERR_LIQ_RADIUS);   // :290 / :273
           int index = (int)(radliq - 1.5);
           if (index == 0) index = 1;
           if (index == 58) index = 57;
@@ -351,9 +358,11 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
           if (fint < 0. && ssacoliq > 1.) ssacoliq = t[T.ssaliq1 + k];
           gliq = t[T.asyliq1 + k] + fint * (t[T.asyliq1 + k + 1] - t[T.asyliq1 + k]);
           forwliq = gliq * gliq;
-          if (extcoliq < 0.0 || ssacoliq > 1.0 || ssacoliq < 0.0 || gliq > 1.0 || gliq < 0.0) report_error(d.err, 13);
+          // :307-311 / :290-294
+          chk(extcoliq < 0.0, RRTMG_ERR_LIQ_EXT_NEG); chk(ssacoliq > 1.0, RRTMG_ERR_LIQ_SSA_GT1); chk(ssacoliq < 0.0, RRTMG_ERR_LIQ_SSA_NEG);
+          chk(gliq > 1.0, RRTMG_ERR_LIQ_ASYM_GT1); chk(gliq < 0.0, RRTMG_ERR_LIQ_ASYM_NEG);
         } else {
-          report_error(d.err, 20);
+          chk(true, RRTMG_ERR_UNSUPPORTED);
         }
         const double tauliqorig = clwp * extcoliq, tauiceorig = ciwp * extcoice;
         const double ssaliq = ssacoliq * (1.0 - forwliq) / (1.0 - forwliq * ssacoliq);
@@ -375,8 +384,12 @@ RRTMG_HD void sw_cloud_layer(const SwDev &d, const SwTab &T, int col, int lay) {
         }
       }
     }
+    // (behind a failed check the band gets the optics of no cloud: the solve kernels run to the end of the call whatever the
+    // flag says, and a negative optical depth would take their table lookups out of bounds)
+    if (e) { tau = 0.0; ssa = 1.0; asy = 0.0; }
     d.ctau[o] = tau; d.cssa[o] = ssa; d.casm[o] = asy;
   }
+  if (e) report_error(d.err, e);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -407,7 +420,7 @@ RRTMG_HD bool kiss_seed_column(int ncol, const double *play, int *err, int col, 
   const long N = ncol;
   const double p1 = play[col] * 1.e2, p2 = play[N + col] * 1.e2;
   const double p3 = play[2l * N + col] * 1.e2, p4 = play[3l * N + col] * 1.e2;
-  if (p1 < p2) { report_error(err, 14); return false; }
+  if (p1 < p2) { report_error(err, RRTMG_ERR_KISS_PRESSURE); return false; }
   k.s1 = (int32_t)((p1 - (double)(int)p1) * 1000000000.0);
   k.s2 = (int32_t)((p2 - (double)(int)p2) * 1000000000.0);
   k.s3 = (int32_t)((p3 - (double)(int)p3) * 1000000000.0);
@@ -450,7 +463,7 @@ RRTMG_HD void kiss_mask_column(int ncol, int nlay, int nsub, int icld, int chang
   for (int g = 0; g < nsub; ++g)
     for (int w = 0; w < nw; ++w) mask[((long)g * nw + w) * N + col] = 0ull;
   if (icld == 0) return;
-  if (L < 4) { report_error(err, 4); return; }
+  if (L < 4) { report_error(err, RRTMG_ERR_ARG); return; }
   Kiss k;
   if (!kiss_seed_column(ncol, play, err, col, k)) return;
   for (int i = 0; i < changeSeed; ++i) (void)kiss_next(k);
@@ -489,7 +502,7 @@ RRTMG_HD void kiss_mask_jump(int ncol, int nlay, int icld, const double *play, c
                              int *err, const uint32_t *jumps, int col, int g) {
   for (int w = 0; w < nw; ++w) mask[((long)g * nw + w) * ncol + col] = 0ull;
   if (icld == 0) return;
-  if (nlay < 4) { report_error(err, 4); return; }
+  if (nlay < 4) { report_error(err, RRTMG_ERR_ARG); return; }
   Kiss k;
   if (!kiss_seed_column(ncol, play, err, col, k)) return;
   kiss_jump(k, jumps + (long)g * kKissJumpWords);

@@ -29,6 +29,8 @@ int main(void) {
   rrtmg_sw_args sw = {0};
   rrtmg_lw_args lw = {0};
   int rc, c, k, b;
+  sw.struct_size = (int32_t)sizeof sw;   /* the header this file was compiled against: the library refuses any other */
+  lw.struct_size = (int32_t)sizeof lw;
 
   /* layer k between interfaces k (below) and k+1 (above); pressures in hPa, level 0 = surface */
   for (c = 0; c < NCOL; ++c) {

@@ -49,20 +49,41 @@ extern "C" {
 #define RRTMG_NBNDLW 16
 #define RRTMG_NGPTLW 140
 
-/* status codes: 0 ok; each former Fortran `stop` site maps to a distinct code */
+/* Status codes: 0 ok.  Every distinct `stop` MESSAGE of the reference (the 61 sites of rrtmg_{sw,lw}_cldprop.f90,
+ * rrtmg_{sw,lw}_cldprmc.f90, mcica_subcol_gen_{sw,lw}.f90, rrtmg_sw_rad.nomcica.f90 carry 20 different texts) has its own
+ * code, and rrtmg_hip_last_error() ends with the reference's text.  Where the reference stops at the first failed check, a
+ * call here returns the first failed check of a (column, layer) in the reference's program order, and the largest such code
+ * over the grid (the checks run in parallel); the context stays usable.  Code 13 (rounds 1-4: "any cloud optical property
+ * out of range") is no longer returned: 30-41 say which. */
 enum {
   RRTMG_OK = 0,
   RRTMG_ERR_HIP = 1,               /* HIP runtime failure (message has the hipError string) */
   RRTMG_ERR_NOT_INITIALISED = 2,   /* *_init not called / tables missing */
   RRTMG_ERR_TABLES = 3,            /* data blob unreadable or malformed */
-  RRTMG_ERR_ARG = 4,               /* bad argument (null pointer, nlay<=0, ...) */
+  RRTMG_ERR_ARG = 4,               /* bad argument (null pointer, nlay<=0, struct_size, ...) */
   RRTMG_ERR_PARTIAL_CLOUD = 10,    /* rrtmg_sw_rad.nomcica.f90:618 'PARTIAL CLOUD NOT ALLOWED' */
-  RRTMG_ERR_ICE_RADIUS = 11,       /* rrtmg_{sw,lw}_cldpr*.f90 'ICE RADIUS OUT OF BOUNDS' */
-  RRTMG_ERR_LIQ_RADIUS = 12,       /* 'LIQUID EFFECTIVE RADIUS OUT OF BOUNDS' */
-  RRTMG_ERR_CLOUD_OPTICS = 13,     /* negative extinction / ssa or g out of [0,1] */
-  RRTMG_ERR_KISS_PRESSURE = 14,    /* mcica_subcol_gen_*.f90 'KISSVEC SEED GENERATOR REQUIRES PMID...' */
-  RRTMG_ERR_ICLD = 15,             /* 'MCICA_SUBCOL: INVALID ICLD' */
-  RRTMG_ERR_UNSUPPORTED = 20       /* option not implemented in this build */
+  RRTMG_ERR_ICE_RADIUS = 11,       /* 'ICE RADIUS OUT OF BOUNDS' (sw_cldprop:194,226 sw_cldprmc:183,213 lw_cldprop:198,209 lw_cldprmc:189,198) */
+  RRTMG_ERR_LIQ_RADIUS = 12,       /* 'LIQUID EFFECTIVE RADIUS OUT OF BOUNDS' (sw_cldprop:290 sw_cldprmc:273 lw_cldprop:253 lw_cldprmc:234) */
+  RRTMG_ERR_KISS_PRESSURE = 14,    /* 'MCICA_SUBCOL: KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS.' (mcica_subcol_gen_sw:355, _lw:328) */
+  RRTMG_ERR_ICLD = 15,             /* 'MCICA_SUBCOL: INVALID ICLD' (mcica_subcol_gen_sw:145, _lw:122) */
+  RRTMG_ERR_INFLAG1_MCICA = 16,    /* 'INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA' (sw_cldprmc:166, lw_cldprmc:172) */
+  RRTMG_ERR_ICE_GEN_SIZE = 17,     /* 'ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS' (sw_cldprop:250 sw_cldprmc:236 lw_cldprop:225 lw_cldprmc:212) */
+  RRTMG_ERR_ICE_RADIUS_SMALL = 18, /* 'ICE RADIUS TOO SMALL' (lw_cldprop:193, lw_cldprmc:185) */
+  RRTMG_ERR_UNSUPPORTED = 20,      /* option without an implementation in RRTMG itself (e.g. shortwave inflag = 1, iceflag = 0) */
+  /* shortwave cloud-optics checks behind each parameterisation (sw_cldprop:216-220,240-244,264-265,270-274,307-311;
+   * sw_cldprmc:204-208,227-231,250-251,256-260,290-294) */
+  RRTMG_ERR_ICE_EXT_NEG = 30,      /* 'ICE EXTINCTION LESS THAN 0.0' */
+  RRTMG_ERR_ICE_SSA_GT1 = 31,      /* 'ICE SSA GRTR THAN 1.0' */
+  RRTMG_ERR_ICE_SSA_NEG = 32,      /* 'ICE SSA LESS THAN 0.0' */
+  RRTMG_ERR_ICE_ASYM_GT1 = 33,     /* 'ICE ASYM GRTR THAN 1.0' */
+  RRTMG_ERR_ICE_ASYM_NEG = 34,     /* 'ICE ASYM LESS THAN 0.0' */
+  RRTMG_ERR_FDELTA_NEG = 35,       /* 'FDELTA LESS THAN 0.0' */
+  RRTMG_ERR_FDELTA_GT1 = 36,       /* 'FDELTA GT THAN 1.0' */
+  RRTMG_ERR_LIQ_EXT_NEG = 37,      /* 'LIQUID EXTINCTION LESS THAN 0.0' */
+  RRTMG_ERR_LIQ_SSA_GT1 = 38,      /* 'LIQUID SSA GRTR THAN 1.0' */
+  RRTMG_ERR_LIQ_SSA_NEG = 39,      /* 'LIQUID SSA LESS THAN 0.0' */
+  RRTMG_ERR_LIQ_ASYM_GT1 = 40,     /* 'LIQUID ASYM GRTR THAN 1.0' */
+  RRTMG_ERR_LIQ_ASYM_NEG = 41      /* 'LIQUID ASYM LESS THAN 0.0' */
 };
 
 typedef struct rrtmg_ctx rrtmg_ctx;
@@ -72,6 +93,11 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal);
 void rrtmg_hip_destroy(rrtmg_ctx *ctx);
 const char *rrtmg_hip_last_error(const rrtmg_ctx *ctx);
 const char *rrtmg_hip_version(void);
+/* Version of the argument structs below (rrtmg_sw_args, rrtmg_lw_args, rrtmg_slab_args): bumped whenever a field is added.
+ * 5 = this header.  A caller can compare it with RRTMG_HIP_ABI_VERSION of the header it was built with; the flux calls
+ * check `struct_size` themselves. */
+#define RRTMG_HIP_ABI_VERSION 5
+int rrtmg_hip_abi_version(void);
 /* HIP stream (hipStream_t) the work of this context is enqueued on (longwave uses a second one in deferred mode). */
 void *rrtmg_hip_stream(rrtmg_ctx *ctx);
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx);
@@ -174,7 +200,11 @@ typedef struct rrtmg_sw_args {
    * (sub-column, column, layer) order (mcica_subcol_gen_sw.f90:360-367), so a shard skips the other shards' draws and
    * reproduces the unsharded masks bit for bit.  kissvec seeds are per column and ignore it. */
   int32_t shard_col0, shard_ncol;
-  int32_t reserved0;
+  /* sizeof(rrtmg_sw_args) of the header the CALLER was compiled against.  0 = the round-3 layout, which ended with the
+   * outputs: the library then reads nothing behind `swhrc` (no unit factors).  Any other value that is not the library's own
+   * sizeof is refused with RRTMG_ERR_ARG -- a caller built against another header never has fields read past its struct.
+   * (This slot was `reserved0`, documented as zero, in every earlier header: old callers keep working.) */
+  int32_t struct_size;
   double adjes, scon, solcycfrac;
   const double *bndsolvar;   /* [14] (host) or NULL -> ones */
   double *indsolvar;         /* [2]  (host) or NULL -> ones; IN/OUT: amplitudes != 1 are rescaled in place once per
@@ -200,7 +230,8 @@ typedef struct rrtmg_sw_args {
    * caller on the host; 0 = the array is in the unit of the reference already.  play, plev *= pressure_scale (Pa -> mbar:
    * 0.01); cicewp, cliqwp *= water_path_scale (kg m^-2 -> g m^-2: 1000); h2ovmr = h2ovmr * h2o_mul / h2o_div (specific
    * humidity -> volume mixing ratio: 28.964 / 18.02, climt/_core/util.py:86).  One rounding per operation, as numpy.
-   * A struct that was zero-initialised gets none of it. */
+   * A struct that was zero-initialised gets none of it.  Read only when struct_size == sizeof(rrtmg_sw_args); with device
+   * pointers (memspace 1) a non-zero factor is an error (RRTMG_ERR_ARG): the caller's device arrays are never modified. */
   double pressure_scale, water_path_scale, h2o_mul, h2o_div;
 } rrtmg_sw_args;
 
@@ -215,7 +246,7 @@ typedef struct rrtmg_lw_args {
   int32_t inflglw, iceflglw, liqflglw;
   int32_t irng, permuteseed;
   int32_t shard_col0, shard_ncol;                    /* see rrtmg_sw_args */
-  int32_t reserved0;
+  int32_t struct_size;                               /* sizeof(rrtmg_lw_args) of the caller's header, or 0 = round-3 layout (see rrtmg_sw_args) */
   const double *play, *plev, *tlay, *tlev, *tsfc;      /* tlev NULL: interpolated on the device from tlay, tsfc, play, plev as
                                                          * climt's get_interface_values does (util.py:89-142) */
   const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;

@@ -73,6 +73,7 @@ class EmuContext:
 
     def sw_init(self, cpdair, blob=None):
         self.cpd_sw = cpdair
+        self.sw_blob = blob or SW_DATA
 
     def lw_init(self, cpdair, blob=None):
         self.cpd_lw = cpdair
@@ -97,7 +98,7 @@ class EmuContext:
         for k, _ in SW_OUT:
             setattr(a, k, out[k].ctypes.data)
         eb = C.create_string_buffer(512)
-        rc = self.lib.emu_sw_fluxes(C.byref(a), SW_DATA.encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
+        rc = self.lib.emu_sw_fluxes(C.byref(a), getattr(self, "sw_blob", SW_DATA).encode(), C.c_double(CPDAIR), _CONST_VEC.ctypes.data_as(C.c_void_p), eb, 512)
         if rc:
             from climt_amd._lib import RRTMGError
             raise RRTMGError(rc, eb.value.decode())
@@ -346,3 +347,78 @@ def require_reference_oracle(kind):
         assert kind == "reference", ("oracle/_ref/librrtmg_{sw,lw}_ref.so are not here: the live oracle would be the C restatement "
                                      "(oracle/), not the reference Fortran.  Build them (oracle/build_ref.sh) or set "
                                      "RRTMG_TEST_ALLOW_PORT_ORACLE=1 to compare with the restatement knowingly.")
+
+
+# ---- every `stop` message of the reference has its own status code (include/rrtmg_hip.h) -----------------------------------
+# (code, text of the reference's stop, spectrum, mcica, changes to the overcast_L60 case, poisoned shortwave table | None |
+#  "host" = checked by the library's host code before any kernel runs: not part of the device-function emulation)
+def _low_first_layer(c):
+    p = np.array(c["play"]); p[0] = p[1] - 1.0   # pressure rising with height in the two lowest layers
+    return dict(play=p, irng=0, permuteseed=3)
+
+
+STOP_CASES = [
+    (10, "PARTIAL CLOUD NOT ALLOWED", "sw", False, lambda c: dict(cldfr=np.where(c["cldfr"] > 0, 0.5, 0.0)), None),
+    (11, "ICE RADIUS OUT OF BOUNDS", "sw", False, lambda c: dict(reice=np.full_like(c["reice"], 500.0)), None),
+    (11, "ICE RADIUS OUT OF BOUNDS", "lw", True, lambda c: dict(reice=np.full_like(c["reice"], 4.0), iceflg=2, irng=0, permuteseed=1), None),
+    (12, "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS", "lw", False, lambda c: dict(reliq=np.full_like(c["reliq"], 1.0)), None),
+    (12, "LIQUID EFFECTIVE RADIUS OUT OF BOUNDS", "sw", True, lambda c: dict(reliq=np.full_like(c["reliq"], 61.0), irng=0, permuteseed=1), None),
+    (14, "KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS", "sw", True, _low_first_layer, None),
+    (14, "KISSVEC SEED GENERATOR REQUIRES PMID FROM BOTTOM FOUR LAYERS", "lw", True, _low_first_layer, None),
+    (16, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA", "sw", True, lambda c: dict(inflg=1, irng=0, permuteseed=1), "host"),
+    (16, "INFLAG = 1 OPTION NOT AVAILABLE WITH MCICA", "lw", True, lambda c: dict(inflg=1, irng=0, permuteseed=1), None),
+    (17, "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS", "sw", False, lambda c: dict(reice=np.full_like(c["reice"], 200.0), iceflg=3), None),
+    (17, "ICE GENERALIZED EFFECTIVE SIZE OUT OF BOUNDS", "lw", False, lambda c: dict(reice=np.full_like(c["reice"], 200.0), iceflg=3), None),
+    (18, "ICE RADIUS TOO SMALL", "lw", False, lambda c: dict(reice=np.full_like(c["reice"], 5.0), iceflg=0), None),
+    (20, "", "sw", False, lambda c: dict(inflg=1), "host"),      # no shortwave implementation of inflag 1 in RRTMG_SW (host check)
+    (20, "", "sw", False, lambda c: dict(iceflg=0), None),       # ... nor of iceflag 0 (device check)
+    (30, "ICE EXTINCTION LESS THAN 0.0", "sw", False, lambda c: dict(iceflg=2), ("sw/cld/extice2", -1.0)),
+    (31, "ICE SSA GRTR THAN 1.0", "sw", False, lambda c: dict(iceflg=2), ("sw/cld/ssaice2", 1.5)),
+    (32, "ICE SSA LESS THAN 0.0", "sw", True, lambda c: dict(iceflg=2, irng=0, permuteseed=1), ("sw/cld/ssaice2", -0.5)),
+    (33, "ICE ASYM GRTR THAN 1.0", "sw", False, lambda c: dict(iceflg=2), ("sw/cld/asyice2", 1.5)),
+    (34, "ICE ASYM LESS THAN 0.0", "sw", False, lambda c: dict(iceflg=3), ("sw/cld/asyice3", -0.5)),
+    (35, "FDELTA LESS THAN 0.0", "sw", False, lambda c: dict(iceflg=3), ("sw/cld/fdlice3", -0.5)),
+    (36, "FDELTA GT THAN 1.0", "sw", True, lambda c: dict(iceflg=3, irng=0, permuteseed=1), ("sw/cld/fdlice3", 1.5)),
+    (37, "LIQUID EXTINCTION LESS THAN 0.0", "sw", False, lambda c: {}, ("sw/cld/extliq1", -1.0)),
+    (38, "LIQUID SSA GRTR THAN 1.0", "sw", False, lambda c: {}, ("sw/cld/ssaliq1", 1.5)),
+    (39, "LIQUID SSA LESS THAN 0.0", "sw", False, lambda c: {}, ("sw/cld/ssaliq1", -0.5)),
+    (40, "LIQUID ASYM GRTR THAN 1.0", "sw", True, lambda c: dict(irng=0, permuteseed=1), ("sw/cld/asyliq1", 1.5)),
+    (41, "LIQUID ASYM LESS THAN 0.0", "sw", False, lambda c: {}, ("sw/cld/asyliq1", -0.5)),
+]
+
+
+def poisoned_sw_blob(path, name, value):
+    """The shortwave data blob with every entry of ONE table replaced by `value` (the cloud-optics checks of cldprop_sw /
+    cldprmc_sw look at numbers interpolated from these tables: with the shipped data they can never fail)."""
+    from tools.pack_tables import Blob, read_blob
+    out = Blob()
+    hit = False
+    for n, arr in read_blob(SW_DATA).items():
+        a = np.array(arr)
+        if n == name:
+            a, hit = np.full_like(a, value), True
+        out.add(n, a)
+    assert hit, name
+    out.write(path)
+    return path
+
+
+def run_stop_case(ctx, case, tmp_path, base=None):
+    """Runs one STOP_CASES entry on `ctx` (Context or EmuContext; its shortwave tables are re-initialised from the poisoned
+    blob when the case has one -- and from the shipped blob again afterwards) and returns the RRTMGError it raised."""
+    import pytest
+    from climt_amd._lib import RRTMGError
+    code, text, which, mcica, change, poison = case
+    c = dict(base) if base is not None else dict(load_ref_case("overcast_L60")[0])
+    c.update(change(c))
+    poison = None if poison == "host" else poison
+    if poison:
+        ctx.sw_init(CPDAIR, blob=poisoned_sw_blob(os.path.join(str(tmp_path), "poisoned_sw.bin"), *poison))
+    try:
+        with pytest.raises(RRTMGError) as e:
+            (ctx.sw_fluxes if which == "sw" else ctx.lw_fluxes)(c, mcica=mcica)
+    finally:
+        if poison:
+            ctx.sw_init(CPDAIR)
+    assert e.value.code == code, (e.value.code, str(e.value))
+    return e.value

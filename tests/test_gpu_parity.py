@@ -9,7 +9,8 @@ import re
 import numpy as np
 import pytest
 
-from helpers import LW_CACHE_CLASSES, LWCLASS_CASES, LWMR_CASES, REF_CASES, ROOT, check_lwclass_case, load_cache_case, load_lwmr_case, load_ref_case, maxdiff
+from helpers import (LW_CACHE_CLASSES, LWCLASS_CASES, LWMR_CASES, REF_CASES, ROOT, STOP_CASES, check_lwclass_case, load_cache_case, load_lwmr_case,
+                     load_ref_case, maxdiff, run_stop_case)
 
 pytestmark = pytest.mark.gpu
 
@@ -358,6 +359,95 @@ def test_error_status_instead_of_stop(gpu_ctx):
         gpu_ctx.sw_fluxes(bad)
     assert e.value.code == 10 and "PARTIAL CLOUD" in str(e.value)
     gpu_ctx.sw_fluxes(c)   # the context stays usable
+
+
+@pytest.fixture(scope="module")
+def stop_ctx():
+    """A context of its own for the `stop` cases: some of them re-initialise the shortwave tables from a poisoned blob."""
+    from climt_amd._lib import Context
+    from oracle.ref_driver import CONSTANTS, CPDAIR
+    ctx = Context(0)
+    ctx.set_constants(**CONSTANTS)
+    ctx.sw_init(CPDAIR)
+    try:
+        ctx.lw_init(CPDAIR)
+    except Exception:
+        pass
+    yield ctx
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", STOP_CASES, ids=lambda c: "%d-%s-%s%s" % (c[0], c[2], c[1].replace(" ", "_")[:28], "-mcica" if c[3] else ""))
+def test_every_stop_message_has_its_own_code_and_text(stop_ctx, gpu_ctx, case, tmp_path):
+    """include/rrtmg_hip.h: one status code per distinct `stop` text of the reference (20 texts at 61 sites), the text itself at
+    the end of rrtmg_hip_last_error(), and a context that stays usable: the next call returns the numbers of a context that
+    never saw the error, bit for bit.  The optics checks behind the cloud parameterisations (30-41) can never fail with the
+    shipped tables; they are reached with a blob in which one table is poisoned."""
+    err = run_stop_case(stop_ctx, case, tmp_path)
+    assert case[1] in str(err), str(err)
+    c, _, _ = load_ref_case("overcast_L60")
+    for which in ("sw", "lw"):
+        a = getattr(stop_ctx, which + "_fluxes")(c)
+        b = getattr(gpu_ctx, which + "_fluxes")(c)
+        assert all(np.array_equal(a[k], b[k]) for k in b), which
+
+
+def test_sub_column_generator_refuses_an_invalid_icld(gpu_ctx):
+    """mcica_subcol_gen_{sw,lw}.f90:145 / :122 'MCICA_SUBCOL: INVALID ICLD' -> RRTMG_ERR_ICLD (15)."""
+    from climt_amd._lib import RRTMGError
+    c, _, _ = load_ref_case("overcast_L60")
+    for which in ("sw", "lw"):
+        with pytest.raises(RRTMGError) as e:
+            gpu_ctx.mcica_mask(which, c["play"], c["cldfr"], icld=7, permuteseed=1, irng=0)
+        assert e.value.code == 15 and "MCICA_SUBCOL: INVALID ICLD" in str(e.value)
+    m = gpu_ctx.mcica_mask("sw", c["play"], c["cldfr"], icld=1, permuteseed=1, irng=0)
+    assert set(np.unique(m)) <= {0.0, 1.0} and m.any()
+
+
+def test_argument_struct_of_another_header_is_refused(gpu_ctx):
+    """`struct_size` (the former reserved0): 0 = the round-3 layout that ended with the outputs -- the unit factors behind them
+    are NOT read; sizeof = this header; anything else is RRTMG_ERR_ARG.  Unit factors with device pointers are an error."""
+    from climt_amd import _lib
+    from climt_amd._lib import RRTMGError
+    lib = gpu_ctx.lib
+    assert lib.rrtmg_hip_abi_version() == 5
+    c, _, _ = load_ref_case("overcast_L60")
+    good = gpu_ctx.sw_fluxes(c)
+
+    def call(struct_size, **scales):
+        nlay, ncol = c["play"].shape
+        a, keep = _lib.SwArgs(), []
+        a.ncol, a.nlay, a.memspace, a.mcica = ncol, nlay, 0, 0
+        a.icld, a.inflgsw, a.iceflgsw, a.liqflgsw, a.dyofyr = 1, 2, 1, 1, 1
+        a.adjes, a.scon, a.solcycfrac = 1.0, 1367.0, 0.0
+        gpu_ctx._fill(a, dict(c, **scales), _lib._SW_FIELDS, _lib._SW_FLAGS, keep)
+        out = {k: np.zeros((nlay + lev, ncol)) for k, lev in _lib.SW_OUT}
+        for k in out:
+            setattr(a, k, out[k].ctypes.data)
+        a.struct_size = struct_size
+        gpu_ctx._ck(lib.rrtmg_hip_sw_fluxes(gpu_ctx.h, C.byref(a)))
+        return out
+
+    full = C.sizeof(_lib.SwArgs)
+    for size in (full - 8, full + 32, 7):
+        with pytest.raises(RRTMGError) as e:
+            call(size)
+        assert e.value.code == 4 and "struct_size" in str(e.value)
+    # a caller built against the round-3 header: whatever lies behind its struct (here: garbage factors) is not read
+    old = call(0, pressure_scale=123.0, water_path_scale=-5.0, h2o_mul=7.0, h2o_div=3.0)
+    assert all(np.array_equal(old[k], good[k]) for k in good)
+    new = call(full)
+    assert all(np.array_equal(new[k], good[k]) for k in good)
+    # device pointers + unit factors: refused before anything is enqueued
+    from climt_amd import _hip
+    dev = {k: _hip.DeviceArray.from_host(v) for k, v in c.items() if isinstance(v, np.ndarray) and k != "lat"}
+    inp = {k: v.ptr for k, v in dev.items()}
+    inp.update({k: v for k, v in c.items() if not isinstance(v, np.ndarray)})
+    inp.update(ncol=c["play"].shape[1], nlay=c["play"].shape[0], pressure_scale=0.01)
+    outs = {k: _hip.DeviceArray((c["play"].shape[0] + lev, c["play"].shape[1])) for k, lev in _lib.SW_OUT}
+    with pytest.raises(RRTMGError) as e:
+        gpu_ctx.sw_fluxes(inp, out={k: v.ptr for k, v in outs.items()}, memspace=1)
+    assert e.value.code == 4 and "host arrays only" in str(e.value)
 
 
 def test_deferred_mode_overlaps_sw_lw_and_reports_errors_at_synchronize(gpu_ctx):
