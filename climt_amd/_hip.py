@@ -91,6 +91,9 @@ class DeviceArray:
         assert arr.nbytes == self.nbytes
         _ck(lib().hipMemcpy(C.c_void_p(self.ptr), C.c_void_p(arr.ctypes.data), C.c_size_t(self.nbytes), C.c_int(1)), "hipMemcpy H2D")
 
+    def zero(self):
+        _ck(lib().hipMemset(C.c_void_p(self.ptr), C.c_int(0), C.c_size_t(self.nbytes)), "hipMemset")
+
     def download(self):
         out = np.empty(self.shape, dtype=self.dtype)
         _ck(lib().hipMemcpy(C.c_void_p(out.ctypes.data), C.c_void_p(self.ptr), C.c_size_t(self.nbytes), C.c_int(2)), "hipMemcpy D2H")

@@ -5,13 +5,19 @@ are serial loops over independent columns), so ranks own contiguous column block
 exchanged while computing.  The only communication reassembles the outputs, and it is optional:
 
     gather = "all"   one ncclAllGather of a flat device buffer holding the rank's 12 (14 with dF/dT) output arrays
+             "direct" the same result by one GROUPED ncclSend / ncclRecv exchange: every rank sends its block straight to each
+                     of its world-1 peers and receives theirs.  xGMI is point to point (7 links per GPU on an 8-GPU node): a
+                     ring all-gather moves (world-1) blocks over ONE link per GPU in world-1 dependent steps, the direct
+                     exchange puts one block on each of the 7 links at once.  The own block is not copied at
+                     all: readers take it from the rank's local buffer
              "root"  the blocks are sent to rank 0 only (grouped ncclSend / ncclRecv)
              "none"  every rank keeps its block (a model that is itself domain-decomposed needs nothing else)
     unpack = True    the gathered buffer -- [rank][array][level][local column], the collective's layout -- is also written out
                      in the boundary layout [array][level][column] by a block-copy kernel behind the gather, on the same
                      stream: a device consumer gets what a single-GPU call would have produced (gathered_device)
 
-`RcclComm` binds librccl.so directly (ctypes: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv) and
+`RcclComm` binds librccl.so directly (ctypes: ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclSend / ncclRecv /
+ncclGroupStart / ncclGroupEnd) and
 runs on its own HIP stream, which is made to wait for the radiation kernels on the device (rrtmg_hip_stream_wait): the gather
 of step i runs under the kernels of step i+1, into the other half of a double buffer.  Any object with the same five methods
 can stand in for it: the world-size-2 CPU tests use one over torch.distributed's gloo (tests/torch_comm.py) -- this package
@@ -45,6 +51,7 @@ COLUMN_AXIS = dict(
 )
 
 
+GATHER_MODES = ("all", "direct", "root", "none")
 TILE = 64   # columns of a wavefront tile (csrc: one wavefront = 64 columns x one work item)
 
 
@@ -191,6 +198,18 @@ class RcclComm:
             self._ck(L.ncclSend(send_ptr, count, self.NCCL_FLOAT64, 0, self.comm, self.stream.s), "ncclSend")
         self._ck(L.ncclGroupEnd(), "ncclGroupEnd")
 
+    def exchange_direct(self, send_ptr, recv_ptr, count):
+        """Every rank r != me receives my send[0:count] and I receive theirs into recv[r * count ...], as ONE group of 2 (world-1)
+        point-to-point operations (RCCL runs the pairs concurrently, each over the xGMI link between the two GPUs);
+        recv[me * count ...] is not written -- the own block stays in `send`."""
+        L = self.lib
+        self._ck(L.ncclGroupStart(), "ncclGroupStart")
+        for d in range(1, self.world):
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world      # (rotated: no two ranks start on the same peer)
+            self._ck(L.ncclSend(send_ptr, count, self.NCCL_FLOAT64, to, self.comm, self.stream.s), "ncclSend")
+            self._ck(L.ncclRecv(recv_ptr + 8 * count * frm, count, self.NCCL_FLOAT64, frm, self.comm, self.stream.s), "ncclRecv")
+        self._ck(L.ncclGroupEnd(), "ncclGroupEnd")
+
     def wait(self):
         self.stream.synchronize()
 
@@ -219,8 +238,8 @@ class ShardedRadiation:
         a block-copy kernel behind the gather on the communicator's stream (rrtmg_hip_copy_blocks): gathered_device(b) /
         gathered_host(b).  Without it the gathered buffer keeps the collective's layout [rank][array][level][local column]
         and only gathered_host reassembles it."""
-        if gather not in ("all", "root", "none"):
-            raise ValueError("gather must be 'all', 'root' or 'none'")
+        if gather not in GATHER_MODES:
+            raise ValueError("gather must be one of %s" % (GATHER_MODES,))
         self.ctx, self.comm, self.gather, self.device = ctx, comm, gather, device
         self.rank, self.world = comm.rank, comm.world
         self.ncol_total, self.nlay = ncol_total, nlay
@@ -235,13 +254,16 @@ class ShardedRadiation:
         self.block = sum((nlay + lev) * self.width for lev in self.levs)       # doubles per rank in the gathered buffer
         self.do_gather = gather != "none" and (self.world > 1 or force)     # force: run the collective with one rank too (tests)
         self.nbuf = nbuf if self.do_gather else 1
-        gathered_here = self.do_gather and (gather == "all" or (gather == "root" and self.rank == 0))
+        gathered_here = self.do_gather and (gather in ("all", "direct") or (gather == "root" and self.rank == 0))
         if device:
             from . import _hip
             self._hip = _hip
             alloc = allocator or (lambda shape: _hip.DeviceArray(shape))     # (a communicator may need to own the buffers)
             self.flat = [alloc((self.block,)) for _ in range(self.nbuf)]
             self.full = [alloc((self.block * self.world,)) if gathered_here else None for _ in range(self.nbuf)]
+            for buf in self.flat:      # a rank with fewer columns than the widest block (or none) sends the padding too: defined bytes
+                if hasattr(buf, "zero"):
+                    buf.zero()
             self.events = [_hip.Event() for _ in range(self.nbuf)]
             self._prev_deferred = ctx.set_deferred(True)
         else:
@@ -267,14 +289,14 @@ class ShardedRadiation:
 
     def unpack_descriptors(self):
         """One block copy per (rank, array): (src_off, dst_off, rows, cols, src_stride, dst_stride, from_own_flat) in doubles.
-        src: the gathered buffer [rank][array][level][that rank's columns]; with gather='root' rank 0's own block never
-        enters it and is read from its local buffer instead (from_own_flat)."""
+        src: the gathered buffer [rank][array][level][that rank's columns]; with gather='root' (rank 0) and gather='direct'
+        (every rank) the own block never enters it and is read from the rank's local buffer instead (from_own_flat)."""
         dst = self.boundary_offsets()
         out = []
         for r in range(self.world):
             rlo, rhi = column_block(self.ncol_total, self.world, r, self.align)
             n_r = rhi - rlo
-            own = self.gather == "root" and r == self.rank
+            own = self.gather in ("root", "direct") and r == self.rank
             for k, (off, rows) in self.offsets(n_r).items():
                 out.append(((0 if own else r * self.block) + off, dst[k][0] + rlo, rows, n_r, n_r, self.ncol_total, own))
         return out
@@ -382,6 +404,8 @@ class ShardedRadiation:
             recv = (self.full[b].ptr if self.device else self.full[b]) if self.full[b] is not None else None
             if self.gather == "all":
                 self.comm.all_gather(send, recv, self.block)
+            elif self.gather == "direct":
+                self.comm.exchange_direct(send, recv, self.block)
             else:
                 self.comm.gather_root(send, recv if recv is not None else 0, self.block)
             if self.unpack:
@@ -413,6 +437,15 @@ class ShardedRadiation:
             self.ctx.set_deferred(prev)
             self._prev_deferred = None
 
+    def gather_ingress_bytes(self):
+        """Bytes this rank RECEIVES per step under the current gather mode (what its xGMI links must deliver while the next
+        step computes): (world-1) blocks for 'all' / 'direct' and for rank 0 of 'root', nothing otherwise."""
+        if not self.do_gather:
+            return 0
+        if self.gather == "root" and self.rank != 0:
+            return 0
+        return 8 * self.block * (self.world - 1)
+
     def local_host(self, b):
         """This rank's outputs of buffer b as numpy arrays [levels][local columns]."""
         flat = self.flat[b].download() if self.device else self.flat[b]
@@ -420,6 +453,7 @@ class ShardedRadiation:
 
     def gathered_host(self, b):
         """The full-grid outputs of buffer b as numpy arrays (ranks that hold them: all, or rank 0 with gather='root')."""
+        # (bytes a gather mode moves over the links, per rank and step: see gather_ingress_bytes)
         if not self.do_gather:
             return self.local_host(b)
         if self.full[b] is None:
@@ -434,8 +468,8 @@ class ShardedRadiation:
             rlo, rhi = column_block(self.ncol_total, self.world, r, self.align)
             n_r = rhi - rlo
             for k, (off, n) in self.offsets(n_r).items():
-                if r == self.rank and self.gather == "root":
-                    cols[k].append(mine[k])     # gather='root' leaves rank 0's own block in place
+                if r == self.rank and self.gather in ("root", "direct"):
+                    cols[k].append(mine[k])     # gather='root' / 'direct' leave the own block in place
                 else:
                     cols[k].append(full[r * self.block + off: r * self.block + off + n * n_r].reshape(n, n_r))
         return {k: np.concatenate(v, axis=1) for k, v in cols.items()}

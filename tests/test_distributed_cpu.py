@@ -42,7 +42,7 @@ def _worker(rank, world, port, q):
     # the product class: three steps (both halves of the double buffer are reused), every gather mode
     name, c, mcica = _cases()[0]
     nlay, ncol = c["play"].shape
-    for mode in ("all", "root", "none"):
+    for mode in ("all", "direct", "root", "none"):
         sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, nlay, gather=mode, device=False)
         sr.set_inputs(c)
         for _ in range(3):
@@ -50,7 +50,7 @@ def _worker(rank, world, port, q):
         sr.finish()
         res["sr_" + mode] = (sr.gathered_host(b), (sr.lo, sr.hi))
     # ... and with the boundary-layout unpack behind the gather (the descriptors the device kernel gets, run by numpy here)
-    for mode in ("all", "root"):
+    for mode in ("all", "direct", "root"):
         sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, nlay, gather=mode, device=False, unpack=True)
         sr.set_inputs(c)
         for _ in range(3):
@@ -89,9 +89,10 @@ def test_two_rank_sharding_is_bit_identical():
     sw0, lw0 = whole["kiss_maxrand"]
     full = dict(sw0); full.update(lw0)
     for rank in (0, 1):
-        got, _ = res[rank]["sr_all"]
-        assert set(got) == set(full)
-        assert all(np.array_equal(got[k], full[k]) for k in full), rank
+        for mode in ("all", "direct"):      # the two algorithms of the same gather: ncclAllGather / grouped send-recv
+            got, _ = res[rank]["sr_" + mode]
+            assert set(got) == set(full)
+            assert all(np.array_equal(got[k], full[k]) for k in full), (rank, mode)
         got, (lo, hi) = res[rank]["sr_none"]
         assert all(np.array_equal(got[k], full[k][:, lo:hi]) for k in full), rank
         got, _ = res[rank]["sr_root"]
@@ -100,14 +101,14 @@ def test_two_rank_sharding_is_bit_identical():
         else:
             assert got is None
         # unpacked: every array [levels][all columns], on every rank that holds the gather
-        for mode in ("all", "root"):
+        for mode in ("all", "direct", "root"):
             got, dev, desc = res[rank]["un_" + mode]
             if mode == "root" and rank != 0:
                 assert got is None and dev is None
                 continue
             assert all(np.array_equal(got[k], full[k]) and np.array_equal(dev[k], full[k]) for k in full), (rank, mode)
             assert len(desc) == 2 * len(full) and sum(d[2] * d[3] for d in desc) == sum(v.size for v in full.values())
-            assert [d[6] for d in desc].count(True) == (len(full) if mode == "root" else 0)      # root: own block from the local buffer
+            assert [d[6] for d in desc].count(True) == (0 if mode == "all" else len(full))      # root / direct: own block from the local buffer
 
 
 def test_mersenne_twister_shards_differ_without_the_skip_ahead():
@@ -181,11 +182,13 @@ def _worker3(rank, world, port, q):
     for ncol in (1000, 100):
         c = make_columns(ncol, 12, cloudy=True, seed=77); c.pop("lat")
         c.update(icld=2, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=1, permuteseed=4242)
-        sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, 12, gather="all", device=False, unpack=True)
-        sr.set_inputs(c)
-        b = sr.step(mcica=True)
-        sr.finish()
-        res[ncol] = (sr.gathered_host(b), (sr.lo, sr.hi))
+        for mode in ("all", "direct"):      # the direct exchange with three ranks: two peers each, rotated; an idle rank takes part
+            sr = ShardedRadiation(ctx, TorchComm(dist, rank, world), ncol, 12, gather=mode, device=False, unpack=True)
+            sr.set_inputs(c)
+            for _ in range(2):
+                b = sr.step(mcica=True)
+            sr.finish()
+            res[(ncol, mode)] = (sr.gathered_host(b), (sr.lo, sr.hi), sr.gather_ingress_bytes())
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res))
@@ -212,9 +215,12 @@ def test_three_ranks_any_column_count_is_bit_identical():
         c.update(icld=2, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=1, permuteseed=4242)
         full = dict(e.sw_fluxes(c, mcica=True)); full.update(e.lw_fluxes(c, mcica=True))
         for rank in range(3):
-            got, block = res[rank][ncol]
-            assert block == blocks[rank]
-            assert all(np.array_equal(got[k], full[k]) for k in full), (ncol, rank)
+            for mode in ("all", "direct"):
+                got, block, ingress = res[rank][(ncol, mode)]
+                assert block == blocks[rank]
+                assert all(np.array_equal(got[k], full[k]) for k in full), (ncol, rank, mode)
+                width = max(hi - lo for lo, hi in blocks)
+                assert ingress == 2 * 8 * sum((12 + lev) * width for lev in (1, 1, 0, 1, 1, 0) * 2)      # two peers' blocks
 
 
 def test_tcp_rendezvous_hands_out_rank0s_bytes():

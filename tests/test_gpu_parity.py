@@ -1226,7 +1226,7 @@ def test_reversed_and_transposed_states_give_the_cached_output_on_the_gpu(patter
                     assert maxdiff(g, w["values"]) <= 1e-8, (pattern, k)
 
 
-@pytest.mark.parametrize("mode", ["all", "root", "none"])
+@pytest.mark.parametrize("mode", ["all", "direct", "root", "none"])
 def test_sharded_radiation_with_rccl_through_ctypes(gpu_ctx, mode):
     """climt_amd.distributed.ShardedRadiation on the device with RcclComm (librccl bound through ctypes, its own stream,
     device-side ordering after the kernels): one rank, collective forced, four steps so that both halves of the double
@@ -1276,8 +1276,8 @@ def test_copy_blocks_kernel_unpacks_a_three_rank_gather(gpu_ctx):
     class FakeComm:
         rank, world, kind, stream = 1, 3, "none", None
     N, L = 1000, 7
-    for mode in ("all", "root"):
-        FakeComm.rank = 1 if mode == "all" else 0
+    for mode in ("all", "direct", "root"):
+        FakeComm.rank = 0 if mode == "root" else (1 if mode == "all" else 2)
         sr = ShardedRadiation(None, FakeComm(), N, L, gather=mode, device=False, unpack=True, idrv=True)
         rng = np.random.default_rng(5)
         full = {k: rng.standard_normal((L + lev, N)) for k, lev in zip(sr.names, sr.levs)}
@@ -1286,7 +1286,7 @@ def test_copy_blocks_kernel_unpacks_a_three_rank_gather(gpu_ctx):
         for r in range(3):
             lo, hi = column_block(N, 3, r)
             for k, (off, rows) in sr.offsets(hi - lo).items():
-                dst = own if (mode == "root" and r == sr.rank) else gathered[r * sr.block:]
+                dst = own if (mode in ("root", "direct") and r == sr.rank) else gathered[r * sr.block:]      # (direct: the own block never enters the gathered buffer)
                 dst[off:off + rows * (hi - lo)] = full[k][:, lo:hi].ravel()
         desc = sr.unpack_descriptors()
         total = sum(rows * N for _, rows in sr.boundary_offsets().values())

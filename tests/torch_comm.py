@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE: communicators over torch.distributed with the interface of climt_amd.distributed.RcclComm
-(all_gather / gather_root / wait / close, .rank / .world / .kind / .stream), so that climt_amd.distributed.ShardedRadiation can
+(all_gather / exchange_direct / gather_root / wait / close, .rank / .world / .kind / .stream), so that climt_amd.distributed.ShardedRadiation can
 be exercised where there is no RCCL: world-size-2 gloo on CPU (tests/test_distributed_cpu.py) and, as an explicit option of
 bench.py (`--comm torch`), two ranks on one GPU.  The product (climt_amd/) imports no torch."""
 import numpy as np
@@ -30,6 +30,22 @@ class TorchComm:
                 recv[r * count:(r + 1) * count] = parts[r].numpy()
         else:
             self.dist.gather(t, None, dst=0)
+
+    def exchange_direct(self, send, recv, count):
+        """point to point, as RcclComm.exchange_direct: the own block is NOT written into recv"""
+        import torch
+        mine = torch.from_numpy(np.ascontiguousarray(send[:count]))
+        got = {}
+        reqs = []
+        for d in range(1, self.world):
+            to, frm = (self.rank + d) % self.world, (self.rank - d) % self.world
+            got[frm] = torch.empty(count, dtype=torch.float64)
+            reqs.append(self.dist.isend(mine, dst=to))
+            reqs.append(self.dist.irecv(got[frm], src=frm))
+        for q in reqs:
+            q.wait()
+        for frm, t in got.items():
+            recv[frm * count:(frm + 1) * count] = t.numpy()
 
     def wait(self):
         pass
@@ -78,6 +94,10 @@ class TorchDeviceComm:
             self.work.append(self.dist.gather(self.bufs[send_ptr][:count], parts, dst=0, async_op=True))
         else:
             self.work.append(self.dist.gather(self.bufs[send_ptr][:count], None, dst=0, async_op=True))
+
+    def exchange_direct(self, send_ptr, recv_ptr, count):
+        """(testing stand-in: the collective writes the own block too, which `direct` readers never look at)"""
+        self.all_gather(send_ptr, recv_ptr, count)
 
     def wait(self):
         for w in self.work:

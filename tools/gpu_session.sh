@@ -23,10 +23,14 @@ for sec in "$@"; do
       timeout 600 python bench.py > $O/${R}_bench_default.log 2>&1; grep "^{" $O/${R}_bench_default.log | tail -1 > $O/${R}_bench_default.json; cut -c1-600 $O/${R}_bench_default.json
       timeout 600 python bench.py --cloudy > $O/${R}_bench_default_cloudy.log 2>&1; grep "^{" $O/${R}_bench_default_cloudy.log | tail -1 > $O/${R}_bench_default_cloudy.json; cut -c1-400 $O/${R}_bench_default_cloudy.json ;;
     dist)
-      for g in all root none; do
-        timeout 300 python bench.py --force-dist --gather $g --no-cpu-baseline --no-extra --steps 100 > $O/${R}_dist_$g.log 2>&1; echo "dist $g rc=$?"; grep "^{" $O/${R}_dist_$g.log | tail -1 | python -c "import json,sys; j=json.loads(sys.stdin.read()); print(round(j['value']), j['ms_per_step'], j['config']['communicator'], j['config']['parallelism'][:60])" || tail -5 $O/${R}_dist_$g.log
-      done
-      timeout 300 python bench.py --force-dist --comm torch --no-cpu-baseline --no-extra --steps 100 > $O/${R}_dist_torch.log 2>&1; grep "^{" $O/${R}_dist_torch.log | tail -1 | cut -c1-200 ;;
+      # ONE run measures every gather mode (bench.py: gather_modes); the second line: two ranks on this one GPU over torch/gloo (testing communicator)
+      timeout 400 python bench.py --force-dist --no-cpu-baseline --no-extra --steps 100 > $O/${R}_dist_modes.log 2>&1; echo "dist rc=$?"; grep "^{" $O/${R}_dist_modes.log | tail -1 > $O/${R}_dist_modes.json
+      python -c "
+import json
+j=json.load(open('$O/${R}_dist_modes.json')); print('headline', j['config']['gather_mode'], round(j['value']), j['ms_per_step'], j['config']['communicator'])
+for m,g in j['gather_modes'].items():
+    if m[0] != '_': print('  %-7s %9d col/s %7.3f ms  ingress %.1f MB/step  achieved %.1f GB/s  ran=%s err=%s' % (m, g['value'], g['ms_per_step'], g['ingress_bytes_per_gpu_per_step']/1e6, g['ingress_GBps_per_gpu_achieved'], g['gather_ran'], g['error']))" || tail -5 $O/${R}_dist_modes.log
+      timeout 300 python bench.py --gpus 2 --share-device --dist-backend gloo --comm torch --no-cpu-baseline --no-extra --steps 50 --min-seconds 1 > $O/${R}_dist_torch.log 2>&1; grep "^{" $O/${R}_dist_torch.log | tail -1 | cut -c1-300 ;;
     sizes)
       for c in 4 5; do
         timeout 600 python bench.py --config $c --no-cpu-baseline --no-extra > $O/${R}_bench_config$c.log 2>&1; grep "^{" $O/${R}_bench_config$c.log | tail -1 > $O/${R}_bench_config$c.json; cut -c1-300 $O/${R}_bench_config$c.json
@@ -39,7 +43,7 @@ for sec in "$@"; do
         for m in ${AB_MODES:-clear cloudy}; do
           mode=""; [ $m = cloudy ] && mode="--cloudy"
           L=$PWD/climt_amd/_lib/ab/$lib; [ $lib = product ] && L=$PWD/climt_amd/_lib/librrtmg_hip.so
-          env $envs RRTMG_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra --steps 150 $mode 2>&1 | tail -1 | python -c "
+          env $envs RRTMG_HIP_LIB=$L timeout 200 python bench.py --no-cpu-baseline --no-extra --no-mcica --steps 150 $mode 2>&1 | tail -1 | python -c "
 import json,sys
 try:
     j=json.loads(sys.stdin.read()); r=j['roofline']

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/hbm_traffic.json and profiles/fp64_flops.json from the PMC passes of tools/gpu_session.sh
+"""profiles/hbm_traffic.json, profiles/fp64_flops.json and profiles/valu_issue.json from the PMC passes of tools/gpu_session.sh
 (profiles/<round>_pmc_{clear,cloudy}_{FETCH,WRITE}_SIZE[_131072].txt, profiles/<round>_pmc_{clear,cloudy}_sq.txt).
 
   traffic  = (2 x FETCH_SIZE + WRITE_SIZE) KiB per launch -- FETCH_SIZE doubled per the gfx950 correction of
@@ -8,6 +8,13 @@
              scratch 9-14 GB per chunk: far beyond the 256 MB Infinity Cache) give the same bytes per column as the
              8192-column ones, so the traffic is HBM traffic.
   flops    = (2 x FMA_F64 + MUL_F64 + ADD_F64 + TRANS_F64) wave instructions x 64 lanes per launch.
+  issue    = profiles/valu_issue.json: per solve kernel the VALU wave instructions of a launch (SQ_INSTS_VALU), the quarter-rate
+             FP64 ones among them (SQ_INSTS_VALU_TRANS_F64: v_rcp / v_rsq / v_sqrt_f64) and issue_cycles = 4 x (VALU - TRANS) +
+             16 x TRANS: a wave instruction occupies its SIMD's VALU for 4 cycles (16 lanes x 4 = 64; FP64 FMA / MUL / ADD run
+             at that rate on gfx950: 78.6 TF = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz), a quarter-rate one for 16.  bench.py
+             divides by 1024 SIMDs and the clock: the launch's VALU issue time per SIMD, whose ratio to the kernel's duration is
+             roofline.issue_frac.  (Cross-check: SQ_ACTIVE_INST_VALU of the same pass, in quad-cycles, x 4 / 1024 gives the same
+             time within 2 %.)
 Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 columns the value is per
 launch of one column chunk.
   "step|<columns>|<levels>|<clear|cloudy>" = the same counters summed over EVERY kernel of one LW+SW step (preparation,
@@ -61,6 +68,8 @@ if len(hashes) != 1 or None in hashes:
 src_hash = hashes.pop()
 
 traffic = {"_doc": "HBM-side bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB from profiles/%s_pmc_*; see tools/make_traffic_json.py" % rnd}
+issue = {"_doc": "VALU issue cycles per launch = 4 x (SQ_INSTS_VALU - SQ_INSTS_VALU_TRANS_F64) + 16 x SQ_INSTS_VALU_TRANS_F64 (wave instructions, summed over "
+                 "the launch) from profiles/%s_pmc_*_sq.txt; / 1024 SIMDs / 2.4 GHz = VALU issue time per SIMD; see tools/make_traffic_json.py" % rnd}
 flops = {"_doc": "FP64 flops per launch = (2 FMA + MUL + ADD + TRANS wave instructions) x 64 from profiles/%s_pmc_*_sq.txt; see tools/make_traffic_json.py" % rnd}
 for mode in ("clear", "cloudy"):
     for ncol, tag in ((8192, ""), (131072, "_131072")):
@@ -76,12 +85,18 @@ for mode in ("clear", "cloudy"):
             terms = {k: (2.0 * fa[k][0] * fa[k][1] + wa.get(k, (0.0, 0))[0] * wa.get(k, (0.0, 0))[1]) * 1024.0 / steps for k in fa}
             traffic["step|%d|60|%s" % (ncol, mode)] = sum(terms.values())
             traffic["step_kernels|%d|60|%s" % (ncol, mode)] = {k: v for k, v in sorted(terms.items(), key=lambda kv: -kv[1]) if v > 1.0e5}
-    sq = {c: get("%s_pmc_%s_sq.txt" % (rnd, mode), c) for c in ("SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64")}
+    sq = {c: get("%s_pmc_%s_sq.txt" % (rnd, mode), c) for c in ("SQ_INSTS_VALU", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_TRANS_F64", "SQ_ACTIVE_INST_VALU")}
+    for k, valu in sq["SQ_INSTS_VALU"].items():
+        trans = sq["SQ_INSTS_VALU_TRANS_F64"].get(k, 0.0)
+        if valu > 1.0e6:
+            issue["%s|8192|60|%s" % (k, mode)] = {"valu": valu, "trans_f64": trans, "issue_cycles": 4.0 * (valu - trans) + 16.0 * trans,
+                                                  "active_inst_valu_quad_cycles": sq["SQ_ACTIVE_INST_VALU"].get(k)}
     for k in sq["SQ_INSTS_VALU_FMA_F64"]:
         f = 64.0 * (2.0 * sq["SQ_INSTS_VALU_FMA_F64"][k] + sq["SQ_INSTS_VALU_MUL_F64"].get(k, 0) + sq["SQ_INSTS_VALU_ADD_F64"].get(k, 0) + sq["SQ_INSTS_VALU_TRANS_F64"].get(k, 0))
         if f > 1.0e6:
             flops["%s|8192|60|%s" % (k, mode)] = f
-traffic["source_hash"] = flops["source_hash"] = src_hash
+traffic["source_hash"] = flops["source_hash"] = issue["source_hash"] = src_hash
 json.dump(traffic, open(os.path.join(ROOT, "profiles", "hbm_traffic.json"), "w"), indent=1)
 json.dump(flops, open(os.path.join(ROOT, "profiles", "fp64_flops.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1)); print(json.dumps(flops, indent=1))
+json.dump(issue, open(os.path.join(ROOT, "profiles", "valu_issue.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1)); print(json.dumps(flops, indent=1)); print(json.dumps(issue, indent=1))
