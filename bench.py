@@ -35,10 +35,11 @@ Prints ONE JSON line on rank 0 (see the driver contract), with
                  / 6.3 TB/s (what this part sustains): how close the step is to a floor made of bytes it moves.
   cpu_baseline : the reference Fortran (oracle/_ref; LW on the synthetic k-tables) timed on the host cores of this box on a
                  bounded sample of the same columns (rank 0, N=1 only).
-                 bound = what holds the dominant kernel (VALU issue for the shortwave kernels, the vector-memory pipeline of
-                 a CU for the longwave ones: docs/EXPERIMENTS.md); issue_frac = its VALU issue time -- (4 x full-rate + 16 x
-                 quarter-rate FP64 wave instructions, SQ pass under profiles/) / 1024 SIMDs / 2.4 GHz -- over its duration:
-                 the fraction that steers work on this path.  achieved / peak / frac stay the contract's HBM definition.
+                 bound = "hbm": the roofline achieved / peak / frac are quoted against, as the contract defines them (hbm | mfma;
+                 there is no matrix arithmetic on this path).  limiter = what actually holds the dominant kernel (VALU issue for
+                 the shortwave kernels, the vector-memory pipeline of a CU for the longwave ones: docs/EXPERIMENTS.md);
+                 issue_frac = its VALU issue time -- (4 x full-rate + 16 x quarter-rate FP64 wave instructions, SQ pass under
+                 profiles/) / 1024 SIMDs / 2.4 GHz -- over its duration: the fraction that steers work on this path.
   mcica        : (N=1, default run) BASELINE.json configs[2] -- McICA liquid+ice clouds, 8192 x 60 -- as a CO-HEADLINE: the same
                  bracket discipline (K-step brackets repeated to --min-seconds), with its own top-level `roofline_mcica`.
   cpu_baseline : the reference Fortran (see above).
@@ -65,8 +66,8 @@ HBM_SUSTAINED = 6.3e12     # what a streaming kernel achieves on this part (MI35
 # and clock are in MI355X_MICROARCH.md, the per-SIMD FP64 rate (a wavefront's FP64 FMA issues over 4 cycles) is AMD's CDNA figure
 FP64_PEAK = 78.6e12
 N_SIMD, CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md): the VALU issue floor below is per SIMD
-# what holds each solve kernel (measured: docs/EXPERIMENTS.md B-D), printed as roofline.bound
-BOUND = {"sw": "valu-issue (FP64): a SIMD's VALU is >90 % busy while the kernel's waves are resident",
+# what holds each solve kernel (measured: docs/EXPERIMENTS.md B-D), printed as roofline.limiter
+LIMITER = {"sw": "valu-issue (FP64): a SIMD's VALU is >90 % busy while the kernel's waves are resident",
          "lw": "vector-memory pipeline of a CU (TA/TD busy 59-85 %, VALU 38 %): latency of four dependent trips per layer at 2 waves per SIMD"}
 FLAGS = dict(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
 
@@ -579,7 +580,7 @@ def main():
                 # quarter-rate FP64 one (v_rcp / v_rsq / v_sqrt_f64) for 16; the work is spread over all 1024 SIMDs
                 issue_ms = (iss["issue_cycles"] / N_SIMD / CLOCK_HZ * 1e3) if iss else None
                 kernels.append({
-                    "kernel": name, "spectrum": which, "bound": BOUND[which], "launches_per_step": launches, "columns_per_launch": N / launches,
+                    "kernel": name, "spectrum": which, "limiter": LIMITER[which], "launches_per_step": launches, "columns_per_launch": N / launches,
                     "algorithmic_bytes_per_column": bpc, "algorithmic_bytes_per_launch": bpc * N / launches,
                     "launch_ms_timed_region": t_ms / launches, "launch_ms_alone": s_ms / launches, "enqueued_first": bool(first),
                     "achieved_GBps_alone": bpc * N / (s_ms * 1e-3) / 1e9, "frac_alone": bpc * N / (s_ms * 1e-3) / HBM_PEAK,
@@ -598,7 +599,7 @@ def main():
             traffic, flops = dom["traffic_per_launch"], dom["fp64_flops_per_launch"]
             step_traffic = traffic_json.get("step|%d|%d|%s" % (N, L, mode))      # FETCH x 2 + WRITE summed over every kernel of a step
             step_bytes = (34 * L + 11) * 8 + (56 * L + 22) * 8
-            return {"bound": dom["bound"], "contract_bound": "hbm", "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            return {"bound": "hbm", "limiter": dom["limiter"], "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms, "duration_source": src,
                     "issue_frac": (dom["valu_issue_ms_per_simd"] / kms) if dom["valu_issue_ms_per_simd"] else None,
                     "issue_frac_serial": dom["issue_frac_alone"],
@@ -622,9 +623,9 @@ def main():
                     "library_source_hash": lib_hash, "counters_source_hash": traffic_json.get("source_hash"), "counters_note": counters_note,
                     "note": "kernel = the solve kernel that takes longer with the GPU to itself (also the larger share in profiles/*_kernel_stats.txt); "
                             "achieved = its ALGORITHMIC bytes per launch / kernel_ms (HIP events around its launches, average over the launches "
-                            "of a call; duration_source says whether that is the timed region or the kernel alone); peak / frac = the contract's "
-                            "HBM roofline (contract_bound), which this path cannot approach on algorithmic bytes (108 FLOP/B); bound = what holds "
-                            "the kernel; issue_frac = VALU issue time per SIMD / kernel_ms (kernels[].issue_frac_alone for both kernels): the "
+                            "of a call; duration_source says whether that is the timed region or the kernel alone); bound = the roofline peak / frac "
+                            "are quoted against, as the contract defines it (HBM: this path cannot approach it on algorithmic bytes, 108 FLOP/B); "
+                            "limiter = what actually holds the kernel; issue_frac = VALU issue time per SIMD / kernel_ms (kernels[].issue_frac_alone for both kernels): the "
                             "fraction that steers work here.  traffic / step_traffic = measured HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, PMC "
                             "passes of this command committed under profiles/); step_hbm_side_frac = step_traffic / ms_per_step / 6.3 TB/s"}
         launches = max(1, ctx.kernel_launches("sw", cloudy=cloudy))      # column chunks per call: one launch of each solve kernel per chunk

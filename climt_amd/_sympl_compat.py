@@ -177,14 +177,22 @@ except ImportError:
             steps, self._dim_lengths, self._wild_names, self._wild_shape = plan
             # components whose library applies unit factors on the device name the inputs it may do that for
             # (climt_amd/rrtmg: pressures, cloud water paths): those go through unconverted, the factor beside them
+            # (climt_amd/rrtmg: pressures, cloud water paths): those go through unconverted under the key name + "@raw", the
+            # factor beside them in "_unit_factors" -- raw[name] itself is then ABSENT, so that whatever reads state[name] on the
+            # host always gets the unit input_properties declares, or a KeyError, never a silently different unit.  Components
+            # that do not opt in see neither key.
             on_device = getattr(self, "_unit_factor_on_device", ())
-            raw["_unit_factors"] = unit_factors = {}
+            unit_factors = {}
+            if on_device:
+                raw["_unit_factors"] = unit_factors
             for name, numeric, factor, order, shape in steps:
                 values = np.asarray(state[name].values)
+                key = name
                 if numeric:
                     values = values.astype(np.float64, copy=False)
                     if factor is not None and name in on_device and values.ndim >= 2:
                         unit_factors[name] = factor
+                        key = name + "@raw"
                     elif factor is not None:
                         if staging is not None and values.ndim >= 2:
                             values = staging.scaled(name, values, factor)
@@ -194,7 +202,7 @@ except ImportError:
                             values = values * factor
                 if order is not None:
                     values = np.transpose(values, order)
-                raw[name] = np.ascontiguousarray(values.reshape(shape)) if shape is not None else values
+                raw[key] = np.ascontiguousarray(values.reshape(shape)) if shape is not None else values
             if staging is not None:
                 staging.wait()
             return raw

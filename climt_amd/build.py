@@ -19,22 +19,27 @@ def _newest(paths):
     return max(os.path.getmtime(p) for p in paths)
 
 
+def _sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
+
+
+def _headers():
+    return sorted(glob.glob(os.path.join(CSRC, "*.h"))) + [os.path.join(HERE, "..", "include", "rrtmg_hip.h")]
+
+
 def source_hash():
-    """sha256 (first 16 hex digits) over every file of climt_amd/csrc and include/rrtmg_hip.h, names and contents: what the
+    """sha256 (first 16 hex digits) over the sources and headers of the library (csrc/*.hip, *.cpp, *.h and include/rrtmg_hip.h), names and contents: what the
     library was built from.  Compiled into rrtmg_hip_version() and written into every profile under profiles/ (tools/
     gpu_session.sh), so that bench.py can tell whether the committed HBM-traffic counters were measured on the library that runs."""
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(CSRC, "*"))) + [os.path.join(HERE, "..", "include", "rrtmg_hip.h")]
-    for f in files:
-        if os.path.isfile(f):
-            h.update(os.path.basename(f).encode() + b"\0")
-            h.update(open(f, "rb").read())
+    for f in _sources() + _headers():      # exactly the files build() compiles and depends on: a stray editor backup or log
+        h.update(os.path.basename(f).encode() + b"\0")   # under csrc/ changes neither the library nor its hash
+        h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=True):
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.cpp")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(HERE, "..", "include", "rrtmg_hip.h")]
+    srcs, hdrs = _sources(), _headers()
     out = os.environ.get("RRTMG_HIP_BUILD_OUT", OUT)
     extra = os.environ.get("RRTMG_HIP_BUILD_FLAGS", "").split()
     if not force and os.path.exists(out) and os.path.getmtime(out) >= _newest(srcs + hdrs):

@@ -1,5 +1,6 @@
 // rrtmg_abi.hip -- extern "C" surface of librrtmg_hip.so (declared in include/rrtmg_hip.h).
 #include <dlfcn.h>
+#include <pthread.h>
 
 #include <cstring>
 #include <mutex>
@@ -120,8 +121,10 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
 // ---- host-pointer inputs (rrtmg_host_inputs.h) ---------------------------------------------------------------------------
 namespace {
 // A few persistent host threads that scan input arrays (created on first use, never joined: they sleep between calls and
-// end with the process).  The caller of wait() works the queue too, so a batch completes even in a process that has no
-// workers (a fork()ed child of a process that had started them).
+// end with the process).  The caller of wait() works its OWN batch's queue too, so a batch completes even in a process whose
+// pool has no workers, and never pays for another context's batch.  fork(): the child gets a fresh pool (pthread_atfork child
+// handler: new mutex, empty queue, workers started on first use) -- the parent's may have been locked by a thread that does
+// not exist in the child.
 struct ScanJob {
   const uint64_t *q = nullptr;
   size_t n = 0;
@@ -132,7 +135,17 @@ constexpr size_t kSliceWords = (size_t)1 << 16;   // 512 KB per task
 class HostPool {
  public:
   struct Batch { std::atomic<long> open{0}; };
-  static HostPool &get() { static HostPool *pool = new HostPool(); return *pool; }
+  static HostPool &get() {
+    HostPool *p = g_pool.load(std::memory_order_acquire);
+    if (p) return *p;
+    static std::once_flag atfork_once;
+    std::call_once(atfork_once, [] { pthread_atfork(nullptr, nullptr, [] { g_pool.store(nullptr, std::memory_order_release); }); });
+    HostPool *fresh = new HostPool();   // (no threads yet: a pool that loses the race below is simply deleted)
+    HostPool *expected = nullptr;
+    if (g_pool.compare_exchange_strong(expected, fresh, std::memory_order_acq_rel)) { fresh->start_workers(); return *fresh; }
+    delete fresh;
+    return *expected;
+  }
   void start(ScanJob *jobs, int njobs, Batch &b) {
     std::lock_guard<std::mutex> lk(m_);
     for (int j = 0; j < njobs; ++j)
@@ -140,17 +153,26 @@ class HostPool {
     cv_.notify_all();
   }
   void wait(Batch &b) {
-    for (;;) {   // help: take tasks (of any batch) until the queue is empty ...
+    for (;;) {   // help with THIS batch's slices until none is queued ...
       Task t;
-      { std::lock_guard<std::mutex> lk(m_); if (tasks_.empty()) break; t = tasks_.back(); tasks_.pop_back(); }
+      {
+        std::lock_guard<std::mutex> lk(m_);
+        size_t k = tasks_.size();
+        while (k > 0 && tasks_[k - 1].batch != &b) --k;
+        if (k == 0) break;
+        t = tasks_[k - 1];
+        tasks_.erase(tasks_.begin() + (long)(k - 1));
+      }
       run(t);
     }
-    while (b.open.load(std::memory_order_acquire) > 0) std::this_thread::yield();   // ... then for the slices workers still hold
+    std::unique_lock<std::mutex> lk(m_);   // ... then sleep until the workers have handed in the slices they still hold
+    done_.wait(lk, [&b] { return b.open.load(std::memory_order_acquire) <= 0; });
   }
 
  private:
   struct Task { ScanJob *job; size_t lo; Batch *batch; };
-  HostPool() {
+  HostPool() = default;
+  void start_workers() {
     unsigned n = std::thread::hardware_concurrency();
     n = n <= 2 ? 1 : (n / 2 > 16 ? 16 : n / 2);
     if (const char *env = getenv("RRTMG_HIP_HOST_THREADS")) { const int v = atoi(env); if (v >= 0 && v <= 64) n = (unsigned)v; }
@@ -163,7 +185,7 @@ class HostPool {
       run(t);
     }
   }
-  static void run(const Task &t) {
+  void run(const Task &t) {
     ScanJob &j = *t.job;
     const size_t hi = t.lo + kSliceWords < j.n ? t.lo + kSliceWords : j.n;
     for (size_t i = t.lo; i < hi && !j.differs.load(std::memory_order_relaxed); i += 4096) {
@@ -172,12 +194,17 @@ class HostPool {
       for (size_t k = i; k < e; ++k) acc |= j.q[k] ^ j.first;
       if (acc) j.differs.store(true, std::memory_order_relaxed);
     }
-    t.batch->open.fetch_sub(1, std::memory_order_release);
+    if (t.batch->open.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // the batch's last slice: wake its waiter
+      std::lock_guard<std::mutex> lk(m_);
+      done_.notify_all();
+    }
   }
+  static std::atomic<HostPool *> g_pool;
   std::mutex m_;
-  std::condition_variable cv_;
+  std::condition_variable cv_, done_;
   std::vector<Task> tasks_;
 };
+std::atomic<HostPool *> HostPool::g_pool{nullptr};
 }  // namespace
 
 void HostInputs::add(const double **slot, const double *host, size_t n, const char *name, bool required, InPolicy policy, double mul, double div) {

@@ -151,28 +151,34 @@ class InputStaging:
 
 # Inputs whose unit factor the library applies on the device after the upload (include/rrtmg_hip.h: pressure_scale,
 # water_path_scale) instead of this package on the host: the stand-in for sympl's extraction (_sympl_compat._extract) hands
-# them over unconverted with the factor in state["_unit_factors"].  (With the real sympl the arrays arrive converted and the
-# dictionary is absent: nothing to do.)
+# them over unconverted under name + "@raw" with the factor in state["_unit_factors"]; state[name] is then absent (nothing on the
+# host can read it in the wrong unit).  (With the real sympl the arrays arrive converted under their names: nothing to do.)
 _PRESSURES = ("air_pressure", "air_pressure_on_interface_levels")
 _WATER_PATHS = ("mass_content_of_cloud_ice_in_atmosphere_layer", "mass_content_of_cloud_liquid_water_in_atmosphere_layer")
 UNIT_FACTOR_ON_DEVICE = _PRESSURES + _WATER_PATHS
+RAW = "@raw"
 
 
 def library_scales(state):
-    """The scale arguments of a host-pointer library call for the raw state of array_call: pressure_scale / water_path_scale
-    from the unit factors left unapplied (one factor per pair of arrays -- a state with, say, the two pressures in different
-    units gets them converted here), and the water-vapour mass -> volume mixing ratio (util.py:86: q * 28.964 / 18.02)."""
+    """-> (scales, arrays): the scale arguments of a host-pointer library call for the raw state of array_call, and the four
+    arrays they apply to.  pressure_scale / water_path_scale come from the unit factors left unapplied -- one factor per pair
+    of arrays: a state with, say, the two pressures in different units gets the unconverted ones converted here, into
+    state[name] -- and h2o_mul / h2o_div are the water-vapour mass -> volume mixing ratio (util.py:86: q * 28.964 / 18.02)."""
     factors = state.get("_unit_factors") or {}
     scales = {"h2o_mul": 28.964, "h2o_div": 18.02}
+    arrays = {}
     for names, key in ((_PRESSURES, "pressure_scale"), (_WATER_PATHS, "water_path_scale")):
+        raw = [state.get(n + RAW) for n in names]
         f = [factors.get(n) for n in names]
-        if f[0] is not None and f[0] == f[1]:
+        if raw[0] is not None and raw[1] is not None and f[0] == f[1]:
             scales[key] = f[0]
+            arrays.update(zip(names, raw))
         else:
-            for n, fac in zip(names, f):
-                if fac is not None:
-                    state[n] = state[n] * fac
-    return scales
+            for n, r, fac in zip(names, raw, f):
+                if r is not None:
+                    state[n] = r * fac      # (a new array in the unit input_properties declares; the caller's is untouched)
+                arrays[n] = state[n]
+    return scales, arrays
 
 
 def output_arrays(pool, output_properties, raw_input_state, input_properties):
@@ -180,6 +186,8 @@ def output_arrays(pool, output_properties, raw_input_state, input_properties):
     lengths = {}
     for name, prop in input_properties.items():
         v = raw_input_state.get(name) if hasattr(raw_input_state, "get") else None
+        if v is None and hasattr(raw_input_state, "get"):
+            v = raw_input_state.get(name + RAW)      # (an input handed over unconverted: same shape)
         if isinstance(v, np.ndarray):
             for dim, n in zip(prop.get("dims", ()), v.shape):
                 lengths[dim] = n

@@ -132,7 +132,7 @@ class RRTMGLongwave(TendencyComponent):
         """Longwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
         # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02 and the unit factors of the pressures and cloud water paths
         # are applied by the library on the device, after the upload (common.library_scales): no host pass over those arrays
-        scales = library_scales(state)
+        scales, unit = library_scales(state)
         Q = state["specific_humidity"]
         n_layers, n_columns = state["air_temperature"].shape
         # calculate_interface_temperature: the log-pressure interpolation (lw/component.py:378-384) is done by the library on
@@ -142,7 +142,7 @@ class RRTMGLongwave(TendencyComponent):
         diagnostics = output_arrays(self._pool, self.diagnostic_properties, state, self.input_properties)
         tendencies = output_arrays(self._pool, self.tendency_properties, state, self.input_properties)
         inp = dict(
-            play=state["air_pressure"], plev=state["air_pressure_on_interface_levels"], tlay=state["air_temperature"],
+            play=unit["air_pressure"], plev=unit["air_pressure_on_interface_levels"], tlay=state["air_temperature"],
             tlev=T_interface, tsfc=state["surface_temperature"], h2o=Q, o3=state["mole_fraction_of_ozone_in_air"],
             co2=state["mole_fraction_of_carbon_dioxide_in_air"], ch4=state["mole_fraction_of_methane_in_air"],
             n2o=state["mole_fraction_of_nitrous_oxide_in_air"], o2=state["mole_fraction_of_oxygen_in_air"],
@@ -150,8 +150,8 @@ class RRTMGLongwave(TendencyComponent):
             cfc22=state["mole_fraction_of_cfc22_in_air"], ccl4=state["mole_fraction_of_carbon_tetrachloride_in_air"],
             emis=state["surface_longwave_emissivity"], cldfr=state["cloud_area_fraction_in_atmosphere_layer"],
             taucld=state["longwave_optical_thickness_due_to_cloud"],
-            cicewp=state["mass_content_of_cloud_ice_in_atmosphere_layer"],
-            cliqwp=state["mass_content_of_cloud_liquid_water_in_atmosphere_layer"],
+            cicewp=unit["mass_content_of_cloud_ice_in_atmosphere_layer"],
+            cliqwp=unit["mass_content_of_cloud_liquid_water_in_atmosphere_layer"],
             reice=state["cloud_ice_particle_size"], reliq=state["cloud_water_droplet_radius"],
             tauaer=state["longwave_optical_thickness_due_to_aerosol"],
             icld=self._cloud_overlap, idrv=self._calc_dflxdt, inflg=self._cloud_optics, iceflg=self._ice_props,

@@ -139,9 +139,9 @@ class RRTMGShortwave(TendencyComponent):
         """Shortwave heating tendency and up/down fluxes (all-sky and clear-sky)."""
         # mass_to_volume_mixing_ratio(q, 18.02) = q * 28.964 / 18.02 and the unit factors of the pressures and cloud water paths
         # are applied by the library on the device, after the upload (common.library_scales): no host pass over those arrays
-        scales = library_scales(state)
+        scales, unit = library_scales(state)
         Q = state["specific_humidity"]
-        assert state["air_pressure"].shape[0] + 1 == state["air_pressure_on_interface_levels"].shape[0]
+        assert unit["air_pressure"].shape[0] + 1 == unit["air_pressure_on_interface_levels"].shape[0]
         # (the reference also interpolates interface temperatures here, sw/component.py:492-496; RRTMG_SW never reads them)
         Tint = None
         # (recycled when the caller has dropped an earlier call's results: the library overwrites every element)
@@ -149,7 +149,7 @@ class RRTMGShortwave(TendencyComponent):
         tendencies = output_arrays(self._pool, self.tendency_properties, state, self.input_properties)
         day_of_year = 0 if self._ignore_day_of_year else state["time"].timetuple().tm_yday
         inp = dict(
-            play=state["air_pressure"], plev=state["air_pressure_on_interface_levels"], tlay=state["air_temperature"], tlev=Tint,
+            play=unit["air_pressure"], plev=unit["air_pressure_on_interface_levels"], tlay=state["air_temperature"], tlev=Tint,
             tsfc=state["surface_temperature"], h2o=Q, o3=state["mole_fraction_of_ozone_in_air"],
             co2=state["mole_fraction_of_carbon_dioxide_in_air"], ch4=state["mole_fraction_of_methane_in_air"],
             n2o=state["mole_fraction_of_nitrous_oxide_in_air"], o2=state["mole_fraction_of_oxygen_in_air"],
@@ -158,8 +158,8 @@ class RRTMGShortwave(TendencyComponent):
             coszen=np.cos(state["zenith_angle"]), cldfr=state["cloud_area_fraction_in_atmosphere_layer"],
             taucld=state["shortwave_optical_thickness_due_to_cloud"], ssacld=state["single_scattering_albedo_due_to_cloud"],
             asmcld=state["cloud_asymmetry_parameter"], fsfcld=state["cloud_forward_scattering_fraction"],
-            cicewp=state["mass_content_of_cloud_ice_in_atmosphere_layer"],
-            cliqwp=state["mass_content_of_cloud_liquid_water_in_atmosphere_layer"],
+            cicewp=unit["mass_content_of_cloud_ice_in_atmosphere_layer"],
+            cliqwp=unit["mass_content_of_cloud_liquid_water_in_atmosphere_layer"],
             reice=state["cloud_ice_particle_size"], reliq=state["cloud_water_droplet_radius"],
             tauaer=state["shortwave_optical_thickness_due_to_aerosol"], ssaaer=state["single_scattering_albedo_due_to_aerosol"],
             asmaer=state["aerosol_asymmetry_parameter"], ecaer=state["aerosol_optical_depth_at_55_micron"],

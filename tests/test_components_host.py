@@ -237,6 +237,35 @@ def test_staged_input_products_and_extraction_plans():
     assert len(comp._plans) == 2 and all(np.array_equal(d0[k].values, d2[k].values) for k in d0)
 
 
+def test_unconverted_inputs_travel_under_raw_keys_only_for_components_that_ask():
+    """the stand-in's extraction hands an input over unconverted (its unit factor applied by the library on the device)
+    only to a component that names it in `_unit_factor_on_device`, and then under name + "@raw" -- state[name] is absent, so
+    nothing on the host can read it in another unit than input_properties declares; every other component sees converted
+    arrays under their names and no extra key."""
+    if sc.HAVE_SYMPL:
+        pytest.skip("real sympl present")
+    from climt_amd.rrtmg.common import RAW, library_scales
+    state, _, _ = load_cache_case("TestRRTMGShortwave", "column")
+    comp = climt_amd.RRTMGShortwave()
+    raw = comp._extract(state)
+    assert "air_pressure" not in raw and raw["air_pressure" + RAW].max() > 5.0e4        # Pa, as the state holds it
+    assert raw["_unit_factors"]["air_pressure"] == pytest.approx(0.01)
+    scales, unit = library_scales(raw)
+    assert scales["pressure_scale"] == pytest.approx(0.01) and unit["air_pressure"] is raw["air_pressure" + RAW]
+    # the two pressures in different units: the pair is converted on the host, into the unit input_properties declares
+    other = dict(state)
+    p = state["air_pressure"]
+    other["air_pressure"] = sc.DataArray(p.values / 100.0, dims=p.dims, attrs={"units": "hPa"})
+    raw2 = comp._extract(other)
+    scales2, unit2 = library_scales(raw2)
+    assert "pressure_scale" not in scales2 and np.allclose(unit2["air_pressure"], p.values.reshape(unit2["air_pressure"].shape) / 100.0)
+    assert np.allclose(unit2["air_pressure_on_interface_levels"].max(), state["air_pressure_on_interface_levels"].values.max() / 100.0)
+    # a component that does not opt in
+    sun = climt_amd.Instellation()
+    sraw = sun._extract(climt_amd.get_default_state([sun]))
+    assert "_unit_factors" not in sraw and not any(k.endswith(RAW) for k in sraw)
+
+
 def test_instellation_time_arithmetic_matches_oracle():
     """days since 2000-01-01 12:00 (the only host arithmetic of the Instellation drop-in), incl. sub-second times."""
     import datetime
