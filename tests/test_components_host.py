@@ -261,9 +261,15 @@ def test_unconverted_inputs_travel_under_raw_keys_only_for_components_that_ask()
     assert "pressure_scale" not in scales2 and np.allclose(unit2["air_pressure"], p.values.reshape(unit2["air_pressure"].shape) / 100.0)
     assert np.allclose(unit2["air_pressure_on_interface_levels"].max(), state["air_pressure_on_interface_levels"].values.max() / 100.0)
     # a component that does not opt in
-    sun = climt_amd.Instellation()
-    sraw = sun._extract(climt_amd.get_default_state([sun]))
-    assert "_unit_factors" not in sraw and not any(k.endswith(RAW) for k in sraw)
+    class Plain(sc.DiagnosticComponent):
+        input_properties = {"air_pressure": {"dims": ["mid_levels", "*"], "units": "mbar"}}
+        diagnostic_properties = {}
+
+        def array_call(self, st):
+            return {}
+    praw = Plain()._extract(state)
+    assert "_unit_factors" not in praw and not any(k.endswith(RAW) for k in praw if isinstance(k, str))
+    assert praw["air_pressure"].max() < 2.0e3          # converted to mbar on the host, under its own name
 
 
 def test_instellation_time_arithmetic_matches_oracle():
