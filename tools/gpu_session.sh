@@ -63,7 +63,7 @@ except Exception as e:
         for variant in overlap serial; do
           vf=""; [ $variant = serial ] && vf="--serial"
           out=$O/prof_${mode}_$variant; rm -rf $out
-          timeout 240 rocprofv3 --kernel-trace --stats -d $out -- python bench.py --no-cpu-baseline --no-extra --steps 40 --warmup 3 $flag $vf > $out.log 2>&1
+          timeout 240 rocprofv3 --kernel-trace --stats -d $out -- python bench.py --no-cpu-baseline --no-extra --no-mcica --steps 40 --warmup 3 $flag $vf > $out.log 2>&1
           grep "^{" $out.log | tail -1 > $O/${R}_bench_${mode}_$variant.json
           stats $out $O/${R}_bench_${mode}_${variant}_kernel_stats.txt
         done
@@ -74,7 +74,7 @@ except Exception as e:
         flag=""; [ $mode = cloudy ] && flag="--cloudy"
         for c in FETCH_SIZE WRITE_SIZE; do
           out=$O/pmc_${mode}_$c$tag; rm -rf $out
-          timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out -- python bench.py --columns $n --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
+          timeout 300 rocprofv3 --kernel-trace --pmc $c -d $out -- python bench.py --columns $n --no-cpu-baseline --no-extra --no-mcica --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
           pmc $out $O/${R}_pmc_${mode}_$c$tag.txt; cat $O/${R}_pmc_${mode}_$c$tag.txt
         done
       done ;;
@@ -84,7 +84,7 @@ except Exception as e:
         i=0
         for P in "SQ_INSTS_VALU SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES"; do
           i=$((i+1)); out=$O/sq_${mode}_$i; rm -rf $out
-          timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
+          timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --no-mcica --serial --steps 3 --warmup 1 --min-seconds 0 $flag > $out.log 2>&1
           pmc $out $O/${R}_sq_${mode}_$i.txt
         done
         cat $O/${R}_sq_${mode}_1.txt $O/${R}_sq_${mode}_2.txt > $O/${R}_pmc_${mode}_sq.txt
