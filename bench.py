@@ -442,8 +442,6 @@ def main():
             modes = ["none"]
             comm = _NoComm(rank, world)
         comm_kind = comm.kind
-        if a.serial:
-            ctx.set_deferred(False)
         cols_in = columns(N, L, cloudy)
 
         def fence(sr):
@@ -470,6 +468,8 @@ def main():
             sr = ShardedRadiation(ctx, comm, N * world, L, gather=mode, allocator=alloc, force=a.force_dist, unpack=not a.no_unpack,
                                   align=64 if N % 64 == 0 else 1)
             assert sr.ncol == N, (sr.ncol, N)
+            if a.serial:
+                ctx.set_deferred(False)      # (ShardedRadiation switches the deferred mode on: --serial wants synchronous SW then LW calls)
             sr.set_inputs(cols_in, already_local=True)
             hw = comm.kind != "rccl" and sr.do_gather      # (nothing to wait for before a gather that does not run)
             planned = sr.gather_ingress_bytes()            # bytes THIS rank (rank 0 prints) receives per step in this mode
