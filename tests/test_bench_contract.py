@@ -98,3 +98,23 @@ def test_one_run_measures_every_gather_mode():
         assert g[m]["gather_ran"] == (m != "none") and g[m]["error"] is None
     assert j["config"]["gather_mode"] in ("all", "direct") and j["config"]["communicator"].endswith("rccl")
     assert abs(j["value"] - g[j["config"]["gather_mode"]]["value"]) < 1e-6 * j["value"]
+
+
+@pytest.mark.gpu
+def test_two_self_spawned_ranks_share_the_gpu_and_print_one_line():
+    """`--gpus 2` without a launcher: bench.py starts its two ranks itself (here both on GPU 0, over torch/gloo with the testing
+    communicator, because RCCL refuses two ranks on one device): ONE JSON line, n_gpus 2, value = columns of both ranks / the
+    slowest rank's time, every gather mode measured with the bytes a rank receives per step (one peer's block)."""
+    p = _run(["--gpus", "2", "--share-device", "--dist-backend", "gloo", "--comm", "torch", "--steps", "4", "--warmup", "1", "--min-seconds", "0.2",
+              "--no-cpu-baseline", "--no-extra"])
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, (p.returncode, p.stderr[-600:])
+    j = _line(p)
+    assert j["n_gpus"] == 2 and j["scaling"] == "weak" and j["config"]["communicator"].startswith("torch.")
+    n = j["config"]["columns_per_gpu"]
+    assert abs(j["value"] - 2 * n / (j["ms_per_step"] * 1e-3)) < 1e-6 * j["value"]
+    g = j["gather_modes"]
+    block = 8 * sum((60 + lev) * n for lev in (1, 1, 0, 1, 1, 0) * 2)
+    for m in ("all", "direct", "root"):
+        assert g[m]["gather_ran"] and g[m]["error"] is None and g[m]["ingress_bytes_per_gpu_per_step"] == block, m
+    assert g["none"]["ingress_bytes_per_gpu_per_step"] == 0 and g["none"]["value"] > g["all"]["value"]
