@@ -1060,6 +1060,41 @@ def _shard_size_checks(gpu_ctx, ncol, nlay, sample, seed):
     assert all(np.array_equal(lw[k][:, perm], lwp[k]) for k in lw)
 
 
+@pytest.mark.parametrize("ncol,nlay", [(131072, 60), (1036800, 100)], ids=["config4_512x256x60", "config5_1440x720x100"])
+def test_the_whole_8_gpu_grids_on_one_gpu_equal_their_eight_blocks(gpu_ctx, ncol, nlay):
+    """BASELINE configs 4 and 5 at FULL size on a single MI355X (288 GB hold them): the unsharded McICA call over the whole grid
+    against (1) the eight tile-aligned blocks `column_block` deals to the 8 ranks of the scaling run, computed one after the other
+    -- bit for bit, i.e. the gathered result of the 8-GPU run IS the single-GPU result --, and (2) the live reference on a
+    strided sample of 2048 columns."""
+    from climt_amd.distributed import COLUMN_AXIS, column_block, slice_columns
+    from climt_amd.synthetic import make_columns
+    from helpers import live_oracle
+    avail = 0
+    for line in open("/proc/meminfo"):
+        if line.startswith("MemAvailable"):
+            avail = int(line.split()[1]) // (1 << 20)
+    if avail < 96:
+        pytest.skip("needs ~40 GB of host memory for the 1440 x 720 x 100 grid (MemAvailable %d GB)" % avail)
+    c = make_columns(ncol, nlay, cloudy=True, seed=20260928); c.pop("lat")
+    c.update(BASE); c.update(irng=0, permuteseed=684)
+    sw, lw = gpu_ctx.sw_fluxes(c, mcica=True), gpu_ctx.lw_fluxes(c, mcica=True)
+    assert all(np.all(np.isfinite(o)) for o in list(sw.values()) + list(lw.values()))
+    for rank in range(8):
+        lo, hi = column_block(ncol, 8, rank)
+        assert lo % 64 == 0 and hi > lo
+        sub = slice_columns(c, lo, hi)
+        s, l = gpu_ctx.sw_fluxes(sub, mcica=True), gpu_ctx.lw_fluxes(sub, mcica=True)
+        assert all(np.array_equal(sw[k][:, lo:hi], s[k]) for k in sw), (rank, lo, hi)
+        assert all(np.array_equal(lw[k][:, lo:hi], l[k]) for k in lw), (rank, lo, hi)
+        del sub, s, l
+    idx = np.arange(0, ncol, ncol // 2048)[:2048]
+    pick = {k: (np.ascontiguousarray(np.take(v, idx, axis=COLUMN_AXIS[k])) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    esw, elw, kind = live_oracle(pick, True, chunk=128)
+    print("oracle:", kind, "sample", len(idx), "of", ncol)
+    _check({k: v[:, idx] for k, v in sw.items()}, esw, tight=1.0e-7)
+    _check({k: v[:, idx] for k, v in lw.items()}, elw, tight=1.0e-7)
+
+
 @pytest.mark.parametrize("ncol,world", [(1000, 3), (777, 8), (100, 3)])
 def test_tile_aligned_blocks_equal_the_whole_for_any_column_count(gpu_ctx, ncol, world):
     """SURVEY 8(e) for a general N: the blocks climt_amd.distributed.column_block deals out (tile-aligned starts) reproduce the
