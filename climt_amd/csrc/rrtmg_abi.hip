@@ -333,6 +333,10 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   if (e != hipSuccess || n <= 0)
     return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));
   if (device_ordinal < 0 || device_ordinal >= n) return c->fail(RRTMG_ERR_ARG, "device ordinal %d out of range (%d devices)", device_ordinal, n);
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) c->device_mem = prop.totalGlobalMem;
+  }
   return ctx_prepare_device(c);
 }
 

@@ -41,6 +41,21 @@ struct rrtmg_ctx {
   // measured 1-3 % faster than 512 on grids of 16 384 ... 131 072 columns (64: the launches no longer fill the GPU)
   int chunk_tiles = 128;
   bool chunk_auto = true;            // false: RRTMG_HIP_CHUNK_TILES was given
+  size_t device_mem = 0;             // total memory of the device (bounds the work space of the large chunks of mixed grids)
+  // Tiles per chunk for a grid that had BOTH kinds of tiles in the previous call (hint_cloudy of ntile cloudy, each kind at
+  // least a sixteenth): every launch of a solve variant costs whole rounds of workgroups that hold a CU for ~0.8 ms, so a
+  // chunk whose 128 tiles split 96 : 32 between the variants pays two rounds for one and a half rounds of work -- large chunks
+  // amortise the rounding (131 072 McICA columns, a quarter of the tiles cloud-free: 55.6 ms at 128 tiles per chunk, 42.0 at
+  // 2048; 1 036 800 x 100: 749 -> 572 ms), at the price of work space (bytes_per_tile x tiles, kept under an eighth of the
+  // device's memory per spectrum).  Grids of one kind keep the small chunks, whose rows stay cached (+2..8 % there).
+  int mixed_chunk_tiles(int chunk_tiles, int ntile, int hint_cloudy, size_t bytes_per_tile) const {
+    if (!chunk_auto || hint_cloudy < 0 || ntile <= chunk_tiles) return chunk_tiles;
+    const int fewer = hint_cloudy < ntile - hint_cloudy ? hint_cloudy : ntile - hint_cloudy;
+    if (16 * fewer < ntile) return chunk_tiles;
+    long cap = (long)((device_mem / 8) / (bytes_per_tile ? bytes_per_tile : 1)) / 128 * 128;
+    if (cap > 2048) cap = 2048;
+    return cap > chunk_tiles ? (int)cap : chunk_tiles;
+  }
   // What the PREVIOUS call of a spectrum [sw|lw] found -- tiles, layers, tiles with a cloud -- for sizing and ordering the
   // launches of the next one.  The count is left in page-locked memory by the call's last kernel (which also clears the counter) and read
   // WITHOUT waiting when the next call is enqueued (stale, or missing, in a loop that runs ahead of the GPU): a hint.  Every

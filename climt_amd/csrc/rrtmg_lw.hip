@@ -7,6 +7,7 @@
 //                          precipitable water -> secdiff, tile cloud flag) on what the layer part left in LDS; non-McICA cloudy
 //                          tiles: cldprop and the rtrnmr overlap factors
 //     lw_cloudmc_kernel    (McICA)                cldprmc band optics per (column, layer)
+//     tile_lists_kernel    <<<1, 64>>>            the chunk's tiles by solve variant, compacted in tile order (LwDev::tlist)
 //     lw_solve_all_kernel  one launch per variant (cloud-free / cloudy tiles): wavefront = tile(64 columns) x work item (4|2
 //                          g-points of a band), workgroup = 4 tiles of one item sharing its k-distribution slice in LDS
 //     lw_fluxheat_kernel   <<<(tiles, levels/15), 16 waves>>>  band / g-point integration per interface + heating rates
@@ -100,14 +101,10 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   const int per = kLwGroupBlocks * T.nitem;
   const int grp = q / per, r = q % per;
   const int k = r / kLwGroupBlocks;
-  const int ctile0 = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;   // first tile (within the chunk) of this workgroup
-  {
-    // workgroup-uniform early exit before the slice is staged: none of this group's tiles is ours
-    bool mine = false;
-    for (int w = 0; w < kLwWgWaves; ++w)
-      if (ctile0 + w < ntile && (d.tile_cld[tile0 + ctile0 + w] != 0) == CLD) mine = true;
-    if (!mine) return;
-  }
+  // this variant's tiles, compacted (LwDev::tlist): the workgroup takes list entries [first, first + kLwWgWaves)
+  const int first = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;
+  const int nmine = d.tcnt[CLD ? 1 : 0];
+  if (first >= nmine) return;   // workgroup-uniform exit before the slice is staged
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int slot = T.sched[k], item = T.item[slot];
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;
@@ -121,8 +118,8 @@ __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_p
   }
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = ctile0 + wave, tile = tile0 + ctile;
-  if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
+  if (first + wave >= nmine) return;
+  const int ctile = d.tlist[(CLD ? d.tcap : 0) + first + wave], tile = tile0 + ctile;
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
@@ -257,7 +254,11 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const int hint_cloudy = (ctx->hint[1].ntile == ntile && ctx->hint[1].nlay == L) ? ctx->hint[1].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
+  chunk_tiles = ctx->mixed_chunk_tiles(chunk_tiles, ntile, clouds ? hint_cloudy : -1, (size_t)kLwNGpt * LF_N * L * 64 * sizeof(double));
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
+  int32_t *tlist = (int32_t *)ctx->buf("lw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
+  if (!tlist) ok = false;
+  d.tcap = ctile; d.tlist = tlist; d.tcnt = tlist ? tlist + 2 * d.tcap : nullptr;
   d.scratch = wd("scratch", (size_t)ctile * kLwNGpt * LF_N * L * 64);
   d.part = wd("part", (size_t)T.nitem * nk * (L + 1) * ctile * 64);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
@@ -318,6 +319,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     hipLaunchKernelGGL(lw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), s, d, T,
                        clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0, keep_layers, t0);
     if (clouds && d.mcica) hipLaunchKernelGGL(lw_cloudmc_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
+    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, s, d.tile_cld + t0, nt, tlist, tlist + 2 * d.tcap, d.tcap);
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
     const int ci = t0 / ctile;

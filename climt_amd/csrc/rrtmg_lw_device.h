@@ -71,6 +71,8 @@ struct LwDev {
   int32_t *ncbands;    // [col]
   double *mr;          // rtrnmr overlap factors [tile][index 0..L+1][MR_N][64] (non-McICA icld >= 2), see lw_mr_column
   int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has cldfr > 0 (selects the solve kernel variant)
+  const int32_t *tlist, *tcnt;   // the chunk's tiles by variant, compacted (see SwDev)
+  int tcap;
   int32_t *ncloudy;    // number of tiles with tile_cld set, counted by the preparation kernels (rrtmg_ctx::CallHint) ...
   int32_t *hint_out;   // ... and where the call's LAST integration launch leaves it for the host (page-locked; nullptr in the others)
   uint64_t *mask;      // [140][nw][col]

@@ -7,6 +7,27 @@
 
 namespace rrtmg {
 
+// The tiles of one column chunk by solve variant, compacted IN TILE ORDER: list[v * cap + i] = the i-th tile (index within the
+// chunk) whose flag is v (0 cloud-free, 1 cloudy), cnt[v] = how many.  One wavefront (ballots + population counts of the lower
+// lanes); launched behind the chunk's preparation kernel, which writes the flags.
+static __global__ void __launch_bounds__(64) tile_lists_kernel(const int32_t *tile_cld, int ntile, int32_t *list, int32_t *cnt, int cap) {
+  const int lane = threadIdx.x;
+  int n0 = 0, n1 = 0;
+  for (int t0 = 0; t0 < ntile; t0 += 64) {
+    const int t = t0 + lane;
+    const bool in = t < ntile;
+    const bool cld = in && tile_cld[t] != 0;
+    const unsigned long long m1 = __ballot(cld), m0 = __ballot(in && !cld);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    if (in) {
+      if (cld) list[cap + n1 + __popcll(m1 & lower)] = t;
+      else list[n0 + __popcll(m0 & lower)] = t;
+    }
+    n0 += __popcll(m0); n1 += __popcll(m1);
+  }
+  if (lane == 0) { cnt[0] = n0; cnt[1] = n1; }
+}
+
 // kissvec sub-columns, one thread per (column, sub-column): grid (nsub, tiles), the sub-column index FASTEST -- the nsub
 // blocks of a tile run back to back and re-read the tile's 64 x nlay cloud fractions from L2 (with tiles fastest the whole
 // cldfr array streamed through once per sub-column: 8 GB per launch at 131072 columns, where it no longer fits the L2s).

@@ -8,8 +8,12 @@
 //                         index words in LDS (laytrop, cloud flag, solar-source layer per band); non-McICA cloudy tiles: the
 //                         band cloud optics
 //     sw_cloud_kernel     (McICA)                 band cloud optics per (column, layer)
+//     tile_lists_kernel   <<<1, 64>>>             the chunk's tiles by solve variant, compacted in tile order (SwDev::tlist)
 //     sw_solve_all_kernel<false> (cloud-free tiles) + sw_solve_cloudy_kernel (cloudy tiles): wavefront = tile(64 columns) x work
-//                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS
+//                         item (4|2 g-points of a band), workgroup = 16 | 8 tiles of one item sharing its tables in LDS;
+//                         a workgroup's tiles are consecutive entries of ITS variant's list, so all of its wavefronts have
+//                         work wherever cloud-free and cloudy tiles interleave (every fourth tile cloud-free: 6 of 8 and
+//                         4 of 16 wavefronts otherwise, in workgroups that hold a whole CU either way)
 //     sw_fluxheat_kernel  <<<(tiles, levels/15), 16 waves>>>  g-point sum per interface + heating rates
 #include <future>
 
@@ -110,15 +114,9 @@ template <bool CLD>
 __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(4))) sw_solve_all_kernel(SwDev d, SwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
   const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x;
-  {
-    // workgroup-uniform early exit before the table is staged: none of this group's tiles is ours
-    bool mine = false;
-    for (int w = 0; w < kSwWgWaves; ++w) {
-      const int t = (q % ngrp) * kSwWgWaves + w;
-      if (t < ntile && (d.tile_cld[tile0 + t] != 0) == CLD) mine = true;
-    }
-    if (!mine) return;
-  }
+  // this variant's tiles, compacted (SwDev::tlist): workgroup (q % ngrp) takes list entries [first, first + kSwWgWaves)
+  const int nmine = d.tcnt[CLD ? 1 : 0], first = (q % ngrp) * kSwWgWaves;
+  if (first >= nmine) return;   // workgroup-uniform exit before the tables are staged
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
   const int k = q / ngrp;
@@ -129,9 +127,9 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   sw_stage_slice(T, item, sh_k, 64 * kSwWgWaves);
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = (q % ngrp) * kSwWgWaves + wave;   // tile within the chunk
+  if (first + wave >= nmine) return;
+  const int ctile = d.tlist[(CLD ? d.tcap : 0) + first + wave];   // tile within the chunk
   const int tile = tile0 + ctile;
-  if (ctile >= ntile || (d.tile_cld[tile] != 0) != CLD) return;
   const int col = tile * 64 + (threadIdx.x & 63);
   if (col >= d.ncol) return;
   double *scr = d.scratch + ((long)ctile * kSwNGpt + item_iw0(item)) * (long)F_NTOT * d.nlay * 64 + (threadIdx.x & 63) * 2;
@@ -149,13 +147,9 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
 constexpr int kC4Waves = 8;
 __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   const int ngrp = (ntile + kC4Waves - 1) / kC4Waves;
-  const int q = blockIdx.x, ctile0 = (q % ngrp) * kC4Waves, k = q / ngrp;
-  {
-    bool mine = false;
-    for (int w = 0; w < kC4Waves; ++w)
-      if (ctile0 + w < ntile && d.tile_cld[tile0 + ctile0 + w] != 0) mine = true;
-    if (!mine) return;
-  }
+  const int q = blockIdx.x, first = (q % ngrp) * kC4Waves, k = q / ngrp;
+  const int nmine = d.tcnt[1];   // the cloudy tiles, compacted (SwDev::tlist)
+  if (first >= nmine) return;
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int id = T.sched[k], item = T.item[id], slot = id;      // one slot per chunk
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
@@ -164,8 +158,8 @@ __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kC4Waves) sh_exp[i] = T.t[T.exp_tbl + i];
   __syncthreads();
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int ctile = ctile0 + wave, tile = tile0 + ctile;
-  if (ctile >= ntile || !d.tile_cld[tile]) return;
+  if (first + wave >= nmine) return;
+  const int ctile = d.tlist[d.tcap + first + wave], tile = tile0 + ctile;
   const int lane = threadIdx.x & 63;
   const int col = tile * 64 + lane;
   if (col >= d.ncol) return;
@@ -354,7 +348,11 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   const int hint_cloudy = (ctx->hint[0].ntile == ntile && ctx->hint[0].nlay == L) ? ctx->hint[0].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
+  chunk_tiles = ctx->mixed_chunk_tiles(chunk_tiles, ntile, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double));
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
+  int32_t *tlist = (int32_t *)ctx->buf("sw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
+  if (!tlist) ok = false;
+  d.tcap = ctile; d.tlist = tlist; d.tcnt = tlist ? tlist + 2 * d.tcap : nullptr;
   d.scratch = wd("scratch", (size_t)ctile * kSwNGpt * F_NTOT * L * 64);
   d.part = wd("part", (size_t)kSwNSlot * 4 * (L + 1) * ctile * 64);
   if (!svar_col.empty()) {   // per-column solar-variability multipliers (rare: facular/sunspot amplitudes != 1)
@@ -409,6 +407,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
     d.col0 = t0 * 64; d.pcols = ctile * 64;
     hipLaunchKernelGGL(sw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), s, d, T, clouds && !d.mcica ? 1 : 0, t0);
     if (clouds && d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
+    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, s, d.tile_cld + t0, nt, tlist, tlist + 2 * d.tcap, d.tcap);
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
     const int ci = t0 / ctile;

@@ -88,6 +88,11 @@ struct SwDev {
   int32_t *laysolfr;   // [14][col], 1-based layer, 0 = source never set
   int32_t *anycld;     // [col] 1 if any layer has cldfr > 0
   int32_t *tile_cld;   // [tile] 1 if any column of the 64-column tile has a cloud (selects the solve kernel variant)
+  // The chunk's tiles by variant, compacted in tile order (tile_lists_kernel, behind the chunk's preparation): tlist[v * tcap + i]
+  // = i-th tile (index within the chunk) of variant v (0 cloud-free, 1 cloudy), tcnt[v] of them.  A solve workgroup takes
+  // consecutive LIST entries, so that all of its wavefronts have work wherever the two kinds of tiles interleave.
+  const int32_t *tlist, *tcnt;
+  int tcap;
   int32_t *ncloudy;    // number of tiles with tile_cld set, counted by the preparation kernels (rrtmg_ctx::CallHint) ...
   int32_t *hint_out;   // ... and where the call's LAST integration launch leaves it for the host (page-locked; nullptr in the others)
   double *cossza;      // [col]
