@@ -1095,6 +1095,33 @@ def test_the_whole_8_gpu_grids_on_one_gpu_equal_their_eight_blocks(gpu_ctx, ncol
     _check({k: v[:, idx] for k, v in lw.items()}, elw, tight=1.0e-7)
 
 
+def test_mixed_grids_switch_to_large_chunks_and_keep_their_bits(gpu_ctx):
+    """A grid with cloud-free AND cloudy tiles: the first call runs in chunks of 128 tiles (nothing is known about the grid), the
+    next ones -- the library has the previous call's count of cloudy tiles -- in large chunks (rrtmg_ctx::mixed_chunk_tiles), with
+    every solve workgroup taking consecutive entries of its variant's compacted tile list.  Same bits either way, also against
+    the interleaving the lists undo (every fourth tile cloud-free), with and without McICA."""
+    from climt_amd.synthetic import make_columns
+    N, L = 32768 + 100, 40          # 514 tiles, the last one ragged
+    c = make_columns(N, L, cloudy=True, seed=31); c.pop("lat"); c.update(BASE); c.update(irng=0, permuteseed=5, icld=2)
+    clear = (np.arange(N) // 64) % 4 == 0
+    for k in ("cldfr", "cicewp", "cliqwp"):
+        c[k][:, clear] = 0.0
+    for mcica in (True, False):
+        cc = dict(c)
+        if not mcica:
+            cc["cldfr"] = (cc["cldfr"] > 0.3).astype(float); cc["icld"] = 1
+        first = dict(gpu_ctx.sw_fluxes(cc, mcica=mcica)); first.update(gpu_ctx.lw_fluxes(cc, mcica=mcica))
+        n_first = gpu_ctx.kernel_launches("sw", cloudy=True)
+        again = dict(gpu_ctx.sw_fluxes(cc, mcica=mcica)); again.update(gpu_ctx.lw_fluxes(cc, mcica=mcica))
+        n_again = gpu_ctx.kernel_launches("sw", cloudy=True)
+        assert n_first == 5 and n_again == 1, (n_first, n_again)          # 514 tiles: 5 chunks of <= 128, then one large chunk
+        assert all(np.array_equal(first[k], again[k]) for k in first), mcica
+        # the cloud-free tiles alone, in a grid of one kind (small chunks, no interleaving): the same columns, the same bits
+        sub = {k: (np.ascontiguousarray(v[..., clear]) if isinstance(v, np.ndarray) else v) for k, v in cc.items()}      # (column = last axis of every array here)
+        alone = dict(gpu_ctx.sw_fluxes(sub, mcica=mcica)); alone.update(gpu_ctx.lw_fluxes(sub, mcica=mcica))
+        assert all(np.array_equal(again[k][:, clear], alone[k]) for k in alone), mcica
+
+
 @pytest.mark.parametrize("ncol,world", [(1000, 3), (777, 8), (100, 3)])
 def test_tile_aligned_blocks_equal_the_whole_for_any_column_count(gpu_ctx, ncol, world):
     """SURVEY 8(e) for a general N: the blocks climt_amd.distributed.column_block deals out (tile-aligned starts) reproduce the
