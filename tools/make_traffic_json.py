@@ -15,8 +15,9 @@
              divides by 1024 SIMDs and the clock: the launch's VALU issue time per SIMD, whose ratio to the kernel's duration is
              roofline.issue_frac.  (Cross-check: SQ_ACTIVE_INST_VALU of the same pass, in quad-cycles, x 4 / 1024 gives the same
              time within 2 %.)
-Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 columns the value is per
-launch of one column chunk.
+Key: "<kernel>|<columns of the call>|<levels>|<clear|cloudy>" (what bench.py looks up); for 131072 clear-sky columns the value is
+per launch of one column chunk (8192 columns), for 131072 McICA columns -- a grid with both kinds of tiles, which runs in ONE
+large chunk from its second call on -- per step.
   "step|<columns>|<levels>|<clear|cloudy>" = the same counters summed over EVERY kernel of one LW+SW step (preparation,
              cloud optics / sub-column masks, both solve variants, flux + heating): sum over kernels of (average per dispatch x
              dispatches) / steps, steps = dispatches of sw_prep_fused_kernel / column chunks of a call (the preparation is
@@ -74,13 +75,20 @@ flops = {"_doc": "FP64 flops per launch = (2 FMA + MUL + ADD + TRANS wave instru
 for mode in ("clear", "cloudy"):
     for ncol, tag in ((8192, ""), (131072, "_131072")):
         fetch, write = get("%s_pmc_%s_FETCH_SIZE%s.txt" % (rnd, mode, tag), "FETCH_SIZE"), get("%s_pmc_%s_WRITE_SIZE%s.txt" % (rnd, mode, tag), "WRITE_SIZE")
-        for k in fetch:
-            b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
-            if b > 1.0e6:
-                traffic["%s|%d|60|%s" % (k, ncol, mode)] = b
         fa, wa = get_all("%s_pmc_%s_FETCH_SIZE%s.txt" % (rnd, mode, tag), "FETCH_SIZE"), get_all("%s_pmc_%s_WRITE_SIZE%s.txt" % (rnd, mode, tag), "WRITE_SIZE")
         chunks = max(1, -(-ncol // (128 * 64)))
         steps = fa.get("rrtmg::sw_prep_fused_kernel", (0, 0))[1] // chunks
+        # McICA: the sub-column mask kernel runs once per spectrum and call whatever the chunking (a grid with both kinds of
+        # tiles -- the 131072-column McICA one -- switches to large chunks after its first call: launches per call vary)
+        per_step = mode == "cloudy" and "rrtmg::kiss_mask_kernel" in fa
+        if per_step:
+            steps = fa["rrtmg::kiss_mask_kernel"][1] // 2
+        for k in fetch:
+            b = (2.0 * fetch[k] + write.get(k, 0.0)) * 1024.0
+            if per_step and ncol > 8192 and steps:      # per STEP (= per launch of the large chunk in steady state)
+                b = (2.0 * fa[k][0] * fa[k][1] + wa.get(k, (0.0, 0))[0] * wa.get(k, (0.0, 0))[1]) * 1024.0 / steps
+            if b > 1.0e6:
+                traffic["%s|%d|60|%s" % (k, ncol, mode)] = b
         if steps and len(fa) > 4:      # (a pass that recorded every kernel, not only the solve kernels)
             terms = {k: (2.0 * fa[k][0] * fa[k][1] + wa.get(k, (0.0, 0))[0] * wa.get(k, (0.0, 0))[1]) * 1024.0 / steps for k in fa}
             traffic["step|%d|60|%s" % (ncol, mode)] = sum(terms.values())
