@@ -98,6 +98,7 @@ __global__ void __launch_bounds__(64) sw_aer_kernel(SwDev d, SwTab T, const doub
 // (measured: -6 % kernel time; with the rows through the scalar cache, an ablation, -10 % was the bound).
 // Launch order: items heaviest first (SwTab::sched), tile groups fastest.  Speed only, never correctness.
 constexpr int kSwWgWaves = 16;
+constexpr int kSwGroupsPerBlock = 8;    // x 16 tiles = 128 tiles per block of the launch order
 constexpr int kExpTblN = 10001;
 // the item's slice of its band's table slab -> LDS: columns ig0 .. ig0+G-1, [nrows][G] (see SwBandTab)
 __device__ __forceinline__ void sw_stage_slice(const SwTab &T, int item, double *sh_k, int nthreads) {
@@ -112,14 +113,22 @@ __device__ __forceinline__ void sw_stage_slice(const SwTab &T, int item, double 
 // wavefront whose tile belongs to the other kernel exits at once.
 template <bool CLD>
 __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_per_eu(4))) sw_solve_all_kernel(SwDev d, SwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
+  // Launch order: BLOCKS of kSwGroupsPerBlock tile groups (128 tiles); within a block work items heaviest first, tile groups
+  // fastest -- a block's prep rows (58 MB at 60 layers) are read by its 32 work items while they are still cached, however many
+  // tiles the launch covers (a large chunk of a grid with both kinds of tiles: 2048 tiles are 0.94 GB of prep rows, re-read
+  // from HBM by every work item in item-major order).  Up to 128 tiles there is one block: the order of rounds 1-4.
   const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
-  const int q = blockIdx.x;
-  // this variant's tiles, compacted (SwDev::tlist): workgroup (q % ngrp) takes list entries [first, first + kSwWgWaves)
-  const int nmine = d.tcnt[CLD ? 1 : 0], first = (q % ngrp) * kSwWgWaves;
-  if (first >= nmine) return;   // workgroup-uniform exit before the tables are staged
+  // (the last block holds the remaining groups: the grid is exactly ngrp x nitem workgroups -- a workgroup that exits at once
+  //  still has to be PLACED with its 138 KB of LDS, and padded grids were measured 75 % slower in round 2)
+  const int q = blockIdx.x, per = kSwGroupsPerBlock * T.nitem, nfull = ngrp / kSwGroupsPerBlock;
+  const int gpb = q < nfull * per ? kSwGroupsPerBlock : ngrp - nfull * kSwGroupsPerBlock, r = q < nfull * per ? q % per : q - nfull * per;
+  const int grp = (q < nfull * per ? q / per : nfull) * kSwGroupsPerBlock + r % gpb;
+  // this variant's tiles, compacted (SwDev::tlist): the workgroup takes list entries [first, first + kSwWgWaves)
+  const int nmine = d.tcnt[CLD ? 1 : 0], first = grp * kSwWgWaves;
+  if (grp >= ngrp || first >= nmine) return;   // workgroup-uniform exit before the tables are staged
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
-  const int k = q / ngrp;
+  const int k = r / gpb;
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int id = T.sched[k], item = T.item[id], slot = id;
   constexpr bool kLdsK = true;
@@ -145,11 +154,14 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
 // workgroups): 1.91 -> 1.73 ms at 8192 columns.  The partial sums leave per chunk, the two pairs' sums added in the order the
 // flux kernel added the pair slots of the round-1 kernel: bit-identical, half the partial-plane traffic.
 constexpr int kC4Waves = 8;
+constexpr int kC4GroupsPerBlock = 16;   // x 8 tiles = 128 tiles per block of the launch order
 __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
   const int ngrp = (ntile + kC4Waves - 1) / kC4Waves;
-  const int q = blockIdx.x, first = (q % ngrp) * kC4Waves, k = q / ngrp;
+  const int q = blockIdx.x, per = kC4GroupsPerBlock * T.nitem, nfull = ngrp / kC4GroupsPerBlock;      // blocks of 128 tiles, see sw_solve_all_kernel
+  const int gpb = q < nfull * per ? kC4GroupsPerBlock : ngrp - nfull * kC4GroupsPerBlock, r = q < nfull * per ? q % per : q - nfull * per;
+  const int grp = (q < nfull * per ? q / per : nfull) * kC4GroupsPerBlock + r % gpb, first = grp * kC4Waves, k = r / gpb;
   const int nmine = d.tcnt[1];   // the cloudy tiles, compacted (SwDev::tlist)
-  if (first >= nmine) return;
+  if (grp >= ngrp || first >= nmine) return;
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int id = T.sched[k], item = T.item[id], slot = id;      // one slot per chunk
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
