@@ -48,11 +48,19 @@ struct rrtmg_ctx {
   // amortise the rounding (131 072 McICA columns, a quarter of the tiles cloud-free: 55.6 ms at 128 tiles per chunk, 42.0 at
   // 2048; 1 036 800 x 100: 749 -> 572 ms), at the price of work space (bytes_per_tile x tiles, kept under an eighth of the
   // device's memory per spectrum).  Grids of one kind keep the small chunks, whose rows stay cached (+2..8 % there).
-  int mixed_chunk_tiles(int chunk_tiles, int ntile, int hint_cloudy, size_t bytes_per_tile) const {
+  // `scratch`: the spectrum's scratch buffer -- what it already holds can be used again; beyond that no more than a third of
+  // the memory that is free right now (a model that has filled the device keeps the small chunks instead of failing).
+  int mixed_chunk_tiles(int chunk_tiles, int ntile, int hint_cloudy, size_t bytes_per_tile, const char *scratch) {
     if (!chunk_auto || hint_cloudy < 0 || ntile <= chunk_tiles) return chunk_tiles;
     const int fewer = hint_cloudy < ntile - hint_cloudy ? hint_cloudy : ntile - hint_cloudy;
     if (16 * fewer < ntile) return chunk_tiles;
-    long cap = (long)((device_mem / 8) / (bytes_per_tile ? bytes_per_tile : 1)) / 128 * 128;
+    size_t budget = device_mem / 8, free_b = 0, total_b = 0;
+    const auto it = bufs.find(scratch);
+    const size_t have = it == bufs.end() ? 0 : it->second.cap;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
+    const size_t room = have > free_b / 3 ? have : free_b / 3;
+    if (room < budget) budget = room;
+    long cap = (long)(budget / (bytes_per_tile ? bytes_per_tile : 1)) / 128 * 128;
     if (cap > 2048) cap = 2048;
     return cap > chunk_tiles ? (int)cap : chunk_tiles;
   }

@@ -360,7 +360,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   const int hint_cloudy = (ctx->hint[0].ntile == ntile && ctx->hint[0].nlay == L) ? ctx->hint[0].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
-  chunk_tiles = ctx->mixed_chunk_tiles(chunk_tiles, ntile, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double));
+  chunk_tiles = ctx->mixed_chunk_tiles(chunk_tiles, ntile, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double), "sw.w.scratch");
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
   int32_t *tlist = (int32_t *)ctx->buf("sw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
   if (!tlist) ok = false;
