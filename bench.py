@@ -685,6 +685,23 @@ def main():
                 if not cloudy and res.get("mcica"):
                     extra["mcica"] = {"moved": "top-level `mcica` (same bracket discipline as the headline) and `roofline_mcica`",
                                       "value": res["mcica"]["value"], "ms_per_step": res["mcica"]["ms_per_step"]}
+                # (a') BASELINE configs[3] WHOLE on this one GPU: 512 x 256 x 60 McICA, cloud-free and cloudy tiles mixed (every fourth
+                # tile of the synthetic field is cloud-free at this size): compacted tile lists + large chunks
+                if not cloudy and a.config == 2 and not (a.columns or a.levels):
+                    try:
+                        save = a.min_seconds
+                        a.min_seconds = min(a.min_seconds, 1.5)
+                        w = device_run(131072, 60, True, 12, 2, a.serial)
+                        a.min_seconds = save
+                        extra["config4_whole_grid_on_one_gpu"] = {
+                            "workload": "rrtmg_lw+sw_mcica_cloudy_131072col_x_60lev (512 x 256 x 60), a quarter of the 64-column tiles cloud-free",
+                            "value": 131072 / (w["ms"] * 1e-3), "unit": "columns/s", "ms_per_step": w["ms"], "steps": 12, "brackets": len(w["brackets"]),
+                            "solve_launches_per_step": ctx.kernel_launches("sw", cloudy=True),
+                            "note": "a grid with both kinds of tiles runs in large chunks from its second call on, every solve workgroup on consecutive "
+                                    "entries of its variant's compacted tile list (2.20e6 columns/s before round 5; 8 x the config-4 shard on 8 GPUs "
+                                    "gives the same numbers bit for bit: tests/test_gpu_parity.py::test_the_whole_8_gpu_grids_on_one_gpu_equal_their_eight_blocks)"}
+                    except Exception as e:   # pragma: no cover
+                        extra["config4_whole_grid_on_one_gpu"] = {"error": repr(e)[:200]}
                 # (b) end to end including PCIe: host-pointer C-ABI (H2D of every input, D2H of the 12 outputs per call)
                 try:
                     c = r["c"]
