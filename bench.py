@@ -220,6 +220,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the end-to-end extras (N=1)")
     ap.add_argument("--no-mcica", action="store_true", help="skip the McICA co-headline of the default run (N=1)")
+    ap.add_argument("--clear-every", type=int, default=0, help="McICA workloads: clouds removed from every N-th 64-column tile -- a grid with both kinds of tiles (docs/EXPERIMENTS.md D)")
     ap.add_argument("--lw-first", action="store_true", help="enqueue the longwave before the shortwave (N=1; experiment)")
     ap.add_argument("--serial", action="store_true", help="synchronous SW then LW calls (no SW||LW stream overlap)")
     ap.add_argument("--sync-every-step", action="store_true", help="host synchronize after every step inside the timed brackets too (N=1)")
@@ -290,6 +291,10 @@ def main():
 
     def columns(ncol, nlay, cld):
         c = make_columns(ncol, nlay, cloudy=cld, seed=20260927 + rank)
+        if cld and a.clear_every > 0:
+            free = (np.arange(ncol) // 64) % a.clear_every == 0
+            for k in ("cldfr", "cicewp", "cliqwp"):
+                c[k][:, free] = 0.0
         c.update(FLAGS)
         c.pop("lat")
         return c

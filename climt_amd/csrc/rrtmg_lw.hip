@@ -97,14 +97,18 @@ static_assert(kLwTileGroup % kLwWgWaves == 0, "tile group must be a whole number
 // MR = true: non-McICA maximum/random overlap (rtrnmr).
 template <bool CLD, bool MR>
 __global__ void __launch_bounds__(64 * kLwWgWaves) __attribute__((amdgpu_waves_per_eu(2))) lw_solve_all_kernel(LwDev d, LwTab T, int tile0, int ntile) {   // tiles tile0 .. tile0 + ntile - 1 (one column chunk)
-  const int q = blockIdx.x;
-  const int per = kLwGroupBlocks * T.nitem;
-  const int grp = q / per, r = q % per;
-  const int k = r / kLwGroupBlocks;
-  // this variant's tiles, compacted (LwDev::tlist): the workgroup takes list entries [first, first + kLwWgWaves)
-  const int first = grp * kLwTileGroup + (r % kLwGroupBlocks) * kLwWgWaves;
+  // this variant's tiles, compacted (LwDev::tlist): nblk workgroups of kLwWgWaves list entries have work; they are the FIRST
+  // nblk x nitem of the dispatch order and dense in it (see sw_solve_all_kernel), in tile groups of kLwGroupBlocks workgroups
+  // -- the last group holds the remaining ones
   const int nmine = d.tcnt[CLD ? 1 : 0];
-  if (first >= nmine) return;   // workgroup-uniform exit before the slice is staged
+  const int nblk = (nmine + kLwWgWaves - 1) / kLwWgWaves;
+  const int q = blockIdx.x;
+  if (q >= nblk * T.nitem) return;   // workgroup-uniform exit before the slice is staged
+  const int per = kLwGroupBlocks * T.nitem, nfull = nblk / kLwGroupBlocks;
+  const int bpg = q < nfull * per ? kLwGroupBlocks : nblk - nfull * kLwGroupBlocks, r = q < nfull * per ? q % per : q - nfull * per;
+  const int grp = q < nfull * per ? q / per : nfull;
+  const int k = r / bpg;
+  const int first = grp * kLwTileGroup + (r % bpg) * kLwWgWaves;
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int slot = T.sched[k], item = T.item[slot];
   const int g = (item >> 16) & 0xf, ig0 = (item >> 8) & 0xff;

@@ -117,15 +117,19 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
   // fastest -- a block's prep rows (58 MB at 60 layers) are read by its 32 work items while they are still cached, however many
   // tiles the launch covers (a large chunk of a grid with both kinds of tiles: 2048 tiles are 0.94 GB of prep rows, re-read
   // from HBM by every work item in item-major order).  Up to 128 tiles there is one block: the order of rounds 1-4.
-  const int ngrp = (ntile + kSwWgWaves - 1) / kSwWgWaves;
-  // (the last block holds the remaining groups: the grid is exactly ngrp x nitem workgroups -- a workgroup that exits at once
-  //  still has to be PLACED with its 138 KB of LDS, and padded grids were measured 75 % slower in round 2)
+  // this variant's tiles, compacted (SwDev::tlist): ngrp groups of kSwWgWaves list entries HAVE work.  The launch was sized for
+  // every tile of the chunk (the host does not know the counts); the workgroups with work are the FIRST ngrp x nitem of the
+  // dispatch order and dense in it, the others exit at once behind them.  (A workgroup that exits at once still has to be
+  // PLACED with its 138 KB of LDS: interleaved with real ones -- a padded grid in round 2, or 8192 McICA columns with every
+  // fourth tile cloud-free before this mapping, 3.64 ms against 2.93 with clouds everywhere -- half the real workgroups wait
+  // for a CU that still holds another.)  The last block of the order holds the remaining groups.
+  const int nmine = d.tcnt[CLD ? 1 : 0];
+  const int ngrp = (nmine + kSwWgWaves - 1) / kSwWgWaves;
   const int q = blockIdx.x, per = kSwGroupsPerBlock * T.nitem, nfull = ngrp / kSwGroupsPerBlock;
+  if (q >= ngrp * T.nitem) return;   // workgroup-uniform exit before the tables are staged
   const int gpb = q < nfull * per ? kSwGroupsPerBlock : ngrp - nfull * kSwGroupsPerBlock, r = q < nfull * per ? q % per : q - nfull * per;
   const int grp = (q < nfull * per ? q / per : nfull) * kSwGroupsPerBlock + r % gpb;
-  // this variant's tiles, compacted (SwDev::tlist): the workgroup takes list entries [first, first + kSwWgWaves)
-  const int nmine = d.tcnt[CLD ? 1 : 0], first = grp * kSwWgWaves;
-  if (grp >= ngrp || first >= nmine) return;   // workgroup-uniform exit before the tables are staged
+  const int first = grp * kSwWgWaves;
   __shared__ double sh_exp[kExpTblN];
   for (int i = threadIdx.x; i < kExpTblN; i += 64 * kSwWgWaves) sh_exp[i] = T.t[T.exp_tbl + i];
   const int k = r / gpb;
@@ -156,12 +160,12 @@ __global__ void __launch_bounds__(64 * kSwWgWaves) __attribute__((amdgpu_waves_p
 constexpr int kC4Waves = 8;
 constexpr int kC4GroupsPerBlock = 16;   // x 8 tiles = 128 tiles per block of the launch order
 __global__ void __launch_bounds__(64 * kC4Waves) __attribute__((amdgpu_waves_per_eu(2, 2))) sw_solve_cloudy_kernel(SwDev d, SwTab T, int tile0, int ntile) {
-  const int ngrp = (ntile + kC4Waves - 1) / kC4Waves;
-  const int q = blockIdx.x, per = kC4GroupsPerBlock * T.nitem, nfull = ngrp / kC4GroupsPerBlock;      // blocks of 128 tiles, see sw_solve_all_kernel
+  const int nmine = d.tcnt[1];   // the cloudy tiles, compacted (SwDev::tlist); the workgroups with work first and dense: see sw_solve_all_kernel
+  const int ngrp = (nmine + kC4Waves - 1) / kC4Waves;
+  const int q = blockIdx.x, per = kC4GroupsPerBlock * T.nitem, nfull = ngrp / kC4GroupsPerBlock;      // blocks of 128 tiles
+  if (q >= ngrp * T.nitem) return;
   const int gpb = q < nfull * per ? kC4GroupsPerBlock : ngrp - nfull * kC4GroupsPerBlock, r = q < nfull * per ? q % per : q - nfull * per;
   const int grp = (q < nfull * per ? q / per : nfull) * kC4GroupsPerBlock + r % gpb, first = grp * kC4Waves, k = r / gpb;
-  const int nmine = d.tcnt[1];   // the cloudy tiles, compacted (SwDev::tlist)
-  if (grp >= ngrp || first >= nmine) return;
   RRTMG_PROFILE_ONLY_ITEM(d, k)
   const int id = T.sched[k], item = T.item[id], slot = id;      // one slot per chunk
   __shared__ __attribute__((aligned(16))) double sh_k[kSwSlabMaxRows * 4];
