@@ -14,8 +14,8 @@ through ctypes, gather of one flat double-buffered device buffer on its own stre
 measures every gather mode with the same brackets -- `all` (ncclAllGather), `direct` (the same result by one grouped
 ncclSend/ncclRecv exchange, a block on each xGMI link at once), `root`, `none` -- and prints them side by side
 (`gather_modes`: columns/s, the bytes a GPU receives per step, the rate that is and the rate the compute alone would need);
-the headline `value` is the mode `--gather` names (default `auto`: the faster of the two algorithms that leave the
-outputs on every GPU, `all` / `direct`).  torch is used ONLY for the launch contract (process group, barrier, max over ranks); the
+the headline `value` is the mode `--gather` names: a fixed mode, `all` by default (`auto` = the faster of `all` / `direct`, a
+best-of-two selection that is not comparable with a fixed-mode line).  torch is used ONLY for the launch contract (process group, barrier, max over ranks); the
 compute path is librrtmg_hip.so and the communicator librccl.so, both through ctypes (if librccl cannot be brought up on every
 rank the run goes on without the gather and the line says so; `--comm torch` is a testing option, tests/torch_comm.py).
 
@@ -212,9 +212,10 @@ def main():
     ap.add_argument("--columns", type=int, default=None, help="columns per GPU (overrides the preset)")
     ap.add_argument("--levels", type=int, default=None)
     ap.add_argument("--cloudy", action="store_true", help="configs[2]: McICA liquid+ice clouds (kissvec)")
-    ap.add_argument("--gather", default="auto", choices=["auto", "all", "direct", "root", "none"],
-                    help="N>1: which gather mode the headline value is quoted on (every mode is measured and printed either way); "
-                         "auto = the faster of `all` (ncclAllGather) and `direct` (grouped ncclSend/ncclRecv)")
+    ap.add_argument("--gather", default="all", choices=["auto", "all", "direct", "root", "none"],
+                    help="N>1: which gather mode the headline value is quoted on (every mode is measured and printed either way): a FIXED "
+                         "mode, `all` (ncclAllGather, what ShardedRadiation does by default) unless asked otherwise; "
+                         "auto = the faster of `all` and `direct` (a best-of-two: comparable only with other auto lines)")
     ap.add_argument("--gather-modes", default="all,direct,root,none", help="N>1: the modes measured in this run (comma-separated; the headline mode is added)")
     ap.add_argument("--no-gather", action="store_true", help="same as --gather none")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -232,6 +233,9 @@ def main():
                     "(default: a block-copy kernel behind the gather writes the boundary layout [array][level][column])")
     ap.add_argument("--rccl-channels", type=int, default=16, help="N>1: NCCL_MAX_NCHANNELS for the gather (each channel occupies a CU while it runs; "
                     "0 = RCCL's default; a value already in the environment wins)")
+    ap.add_argument("--contract-arrays", action="store_true", help="N=1: also hand over the band arrays SURVEY 8(d)'s contract bytes count and the synthetic columns "
+                    "do not have -- zero `taucld` (LW 16 x L, SW 14 x L) and LW `tauaer` (16 x L) device arrays -- so that the kernels really read them")
+    ap.add_argument("--no-comm-selftest", action="store_true", help="N>1: skip the communicator self-test (every gather mode once on a 1 KB pattern, checked on every rank, before the brackets)")
     ap.add_argument("--min-seconds", type=float, default=3.0, help="timed region: brackets of K steps are repeated until this much time is covered")
     a = ap.parse_args()
     preset = {2: (8192, 60, False), 3: (8192, 60, True), 4: (16384, 60, True), 5: (129600, 100, True)}[a.config]
@@ -306,10 +310,19 @@ def main():
         inp.update(ncol=c["play"].shape[1], nlay=c["play"].shape[0])
         return dev, inp
 
+    def contract_inputs(dev, inp):
+        """--contract-arrays: (sw inputs, lw inputs) with the zero band arrays of the contract figure resident as well"""
+        nlay, ncol = inp["nlay"], inp["ncol"]
+        for name, nb in (("taucld_sw", 14), ("taucld_lw", 16), ("tauaer_lw", 16)):
+            dev[name] = _hip.DeviceArray((nlay * ncol * nb,))
+            dev[name].zero()
+        return dict(inp, taucld=dev["taucld_sw"].ptr), dict(inp, taucld=dev["taucld_lw"].ptr, tauaer=dev["tauaer_lw"].ptr)
+
     def device_run(ncol, nlay, cld, steps, warmup, serial):
         """Single-GPU device-resident loop: -> (ms per step from the whole region, per-step ms list, kernel ms lists)."""
         c = columns(ncol, nlay, cld)
         dev, inp = resident(c)
+        inp_sw, inp_lw = contract_inputs(dev, inp) if a.contract_arrays else (inp, inp)
         sizes = [(k, (nlay + lev) * ncol) for k, lev in SW_OUT] + [(k, (nlay + lev) * ncol) for k, lev in LW_OUT]
         flat = _hip.DeviceArray((sum(s for _, s in sizes),))
         off, so, lo = 0, {}, {}
@@ -322,11 +335,11 @@ def main():
         def enqueue():
             t = time.perf_counter()
             if a.lw_first:
-                ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
-            ctx.sw_fluxes(inp, mcica=cld, out=so, memspace=1)
+                ctx.lw_fluxes(inp_lw, mcica=cld, out=lo, memspace=1)
+            ctx.sw_fluxes(inp_sw, mcica=cld, out=so, memspace=1)
             enq[0] += time.perf_counter() - t
             if not a.lw_first:
-                ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
+                ctx.lw_fluxes(inp_lw, mcica=cld, out=lo, memspace=1)
             enq[1] += time.perf_counter() - t
             enq[2] += 1
 
@@ -372,12 +385,13 @@ def main():
         ctx.set_deferred(False)
         ssw, slw = [], []
         for _ in range(3):      # kernel durations without the SW||LW overlap, for reference
-            ctx.sw_fluxes(inp, mcica=cld, out=so, memspace=1)
-            ctx.lw_fluxes(inp, mcica=cld, out=lo, memspace=1)
+            ctx.sw_fluxes(inp_sw, mcica=cld, out=so, memspace=1)
+            ctx.lw_fluxes(inp_lw, mcica=cld, out=lo, memspace=1)
             ssw.append(ctx.kernel_ms("sw", cloudy=cld))
             slw.append(ctx.kernel_ms("lw", cloudy=cld))
         n_all = max(1, enq[2])
-        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0])
+        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0],
+                    lanes=(ctx.chunk_lanes("sw"), ctx.chunk_lanes("lw")))
 
     def pick_steps(ncol, nlay, cld):
         """Steps per bracket: about 1.5 s worth (estimated from the large-grid rates of DESIGN.md 5); brackets repeat to --min-seconds."""
@@ -447,6 +461,21 @@ def main():
             modes = ["none"]
             comm = _NoComm(rank, world)
         comm_kind = comm.kind
+        # first-execution insurance: before the brackets every gather mode runs ONCE on a 1 KB pattern (rank id in
+        # every word) and is checked on every rank; the line says per mode and rank what happened -- so that the first run on
+        # more than one GPU names the collective that misbehaved instead of only "gather switched off"
+        comm_selftest_result = None
+        if comm.kind != "none" and not a.no_comm_selftest:
+            from climt_amd.distributed import comm_selftest
+            try:
+                mine = comm_selftest(comm, alloc=alloc)
+            except Exception as e:      # pragma: no cover
+                mine = {"all": "FAIL on rank %d: %r" % (rank, e)}
+            every = [None] * world
+            dist.all_gather_object(every, mine)
+            comm_selftest_result = {m: ("OK" if all(r.get(m) == "OK" for r in every) else [r.get(m) for r in every if r.get(m) != "OK"])
+                                    for m in ("all", "direct", "root")}
+            comm_selftest_result["ranks"] = world
         cols_in = columns(N, L, cloudy)
 
         def fence(sr):
@@ -604,6 +633,14 @@ def main():
             traffic, flops = dom["traffic_per_launch"], dom["fp64_flops_per_launch"]
             step_traffic = traffic_json.get("step|%d|%d|%s" % (N, L, mode))      # FETCH x 2 + WRITE summed over every kernel of a step
             step_bytes = (34 * L + 11) * 8 + (56 * L + 22) * 8
+            # the bytes of the arrays this run really hands over (climt_amd.synthetic.make_columns + the 12 outputs): the contract
+            # figure also counts `taucld` (LW 16L, SW 14L) and LW `tauaer` (16L), which the synthetic columns do not have
+            # (--contract-arrays adds them as zero device arrays), and does not count the interface temperatures, which they do
+            extra_lw, extra_sw = (32 * L, 14 * L) if a.contract_arrays else (0, 0)
+            shipped_lw = (17 * L + (L + 1) + (L + 1) + 1 + 16 + extra_lw + 6 * L + 4) * 8      # 12 level + 5 cloud arrays, plev, tlev, tsfc, emis(16) | outputs
+            shipped_sw = (13 * L + (L + 1) + 5 + extra_sw + 6 * L + 4) * 8                      # 8 level + 5 cloud arrays, plev, 4 albedos + coszen | outputs
+            shipped = shipped_lw + shipped_sw
+            issue_sum = sum(k["valu_issue_ms_per_simd"] for k in kernels) if all(k["valu_issue_ms_per_simd"] for k in kernels) else None
             return {"bound": "hbm", "limiter": dom["limiter"], "kernel": dom["kernel"], "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                     "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic, "kernel_ms": kms, "duration_source": src,
                     "issue_frac": (dom["valu_issue_ms_per_simd"] / kms) if dom["valu_issue_ms_per_simd"] else None,
@@ -618,6 +655,14 @@ def main():
                     # over the step time, and the bytes it actually moves against what the memory system sustains
                     "step_algorithmic_bytes_per_column": step_bytes,
                     "step_frac": step_bytes * N / (ms * 1e-3) / HBM_PEAK,
+                    "algorithmic_bytes_shipped_per_column": shipped,
+                    "algorithmic_bytes_shipped_terms": {"lw": shipped_lw, "sw": shipped_sw, "contract_arrays_resident": bool(a.contract_arrays),
+                                                        "note": "arrays this run hands over and gets back, per column: LW 12 level + 5 cloud-physics arrays, plev, tlev, tsfc, emis(16), "
+                                                                "6 outputs; SW 8 level + 5 cloud-physics arrays, plev, 4 albedos, coszen, 6 outputs.  The contract figure "
+                                                                "(step_algorithmic_bytes_per_column, SURVEY 8d) also counts taucld (LW 16L, SW 14L) and LW tauaer (16L), which "
+                                                                "the synthetic columns do not create -- `--contract-arrays` makes them resident as zeros and read -- and leaves tlev out"},
+                    "step_frac_on_shipped_bytes": shipped * N / (ms * 1e-3) / HBM_PEAK,
+                    "step_issue_frac": (issue_sum / ms) if issue_sum else None,
                     "step_traffic": step_traffic,
                     "step_traffic_over_algorithmic": (step_traffic / (step_bytes * N)) if step_traffic else None,
                     "step_hbm_side_frac": (step_traffic / (ms * 1e-3) / HBM_SUSTAINED) if step_traffic else None,
@@ -630,8 +675,9 @@ def main():
                             "achieved = its ALGORITHMIC bytes per launch / kernel_ms (HIP events around its launches, average over the launches "
                             "of a call; duration_source says whether that is the timed region or the kernel alone); bound = the roofline peak / frac "
                             "are quoted against, as the contract defines it (HBM: this path cannot approach it on algorithmic bytes, 108 FLOP/B); "
-                            "limiter = what actually holds the kernel; issue_frac = VALU issue time per SIMD / kernel_ms (kernels[].issue_frac_alone for both kernels): the "
-                            "fraction that steers work here.  traffic / step_traffic = measured HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, PMC "
+                            "limiter = what actually holds the kernel; issue_frac = VALU issue time per SIMD / kernel_ms (kernels[].issue_frac_alone for both kernels), "
+                            "step_issue_frac = the two solve kernels' VALU issue time per SIMD summed / ms_per_step: the fractions that steer work here; "
+                            "step_frac is quoted on the contract's bytes, step_frac_on_shipped_bytes on the arrays this run really hands over.  traffic / step_traffic = measured HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, PMC "
                             "passes of this command committed under profiles/); step_hbm_side_frac = step_traffic / ms_per_step / 6.3 TB/s"}
         launches = max(1, ctx.kernel_launches("sw", cloudy=cloudy))      # column chunks per call: one launch of each solve kernel per chunk
         roofline = roofline_block(N, L, cloudy, r, ms, launches)
@@ -649,6 +695,8 @@ def main():
                        "columns_per_gpu": N, "levels": L, "parallelism": par,
                        "communicator": (comm_note + comm_kind) if comm_kind else None,
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
+                       "chunk_lanes": {"sw": r["lanes"][0], "lw": r["lanes"][1], "note": "column chunks in flight at once per spectrum (2: a grid of >= 2 chunks "
+                                       "runs its even and odd chunks on two streams of the spectrum, each with its own work space)"} if r.get("lanes") else None,
                        "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
                        "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
                        "host_sync": ("after every step" if (a.serial or a.sync_every_step or (multi and host_wait)) else
@@ -664,6 +712,7 @@ def main():
             res["config"]["gathered_layout"] = ("boundary [array][level][column] (block-copy kernel behind the gather)" if r["unpack"] else
                                                 "collective [rank][array][level][local column]") if r["gathered"] else None
             res["config"]["gather_mode"] = a.gather
+            res["comm_selftest"] = comm_selftest_result
             res["gather_modes"] = r.get("gather_modes")
             res["extra"] = {"gather_none": r.get("gather_none"),
                             "how_to_scale": "per-GPU work is fixed (weak scaling): `--config 4` = 512x256x60 over 8 GPUs (16384 columns each), `--config 5` = "

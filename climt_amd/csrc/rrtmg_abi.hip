@@ -69,6 +69,20 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   return RRTMG_OK;
 }
 
+int ctx_fork_lane(rrtmg_ctx *ctx, int which, hipStream_t s) {
+  if (!ctx->stream_aux[which]) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_aux[which], hipStreamNonBlocking));
+  for (int k = 0; k < 2; ++k)
+    if (!ctx->lane_ev[which][k]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[which][k], hipEventDisableTiming));
+  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which][0], s));
+  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_aux[which], ctx->lane_ev[which][0], 0));
+  return RRTMG_OK;
+}
+int ctx_join_lane(rrtmg_ctx *ctx, int which, hipStream_t s) {
+  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which][1], ctx->stream_aux[which]));
+  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->lane_ev[which][1], 0));
+  return RRTMG_OK;
+}
+
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host) {
   // A destination that is page-locked memory the runtime knows (hipHostMalloc / hipHostRegister: the components' output pool
   // hands such arrays out) takes its copy directly; the others go through the staging buffer.
@@ -134,7 +148,11 @@ struct ScanJob {
 constexpr size_t kSliceWords = (size_t)1 << 16;   // 512 KB per task
 class HostPool {
  public:
-  struct Batch { std::atomic<long> open{0}; };
+  struct Task { ScanJob *job; size_t lo; };
+  // A batch owns its slices: `next` is a cursor into `tasks` (both under the pool's mutex), so the waiter takes from its OWN
+  // batch and a worker from the newest batch that has any left in O(1) -- no scan of, and no erase from, a queue shared by
+  // every context while the workers need the same lock.
+  struct Batch { std::atomic<long> open{0}; std::vector<Task> tasks; size_t next = 0; };
   static HostPool &get() {
     HostPool *p = g_pool.load(std::memory_order_acquire);
     if (p) return *p;
@@ -149,29 +167,35 @@ class HostPool {
   void start(ScanJob *jobs, int njobs, Batch &b) {
     std::lock_guard<std::mutex> lk(m_);
     for (int j = 0; j < njobs; ++j)
-      for (size_t lo = 0; lo < jobs[j].n; lo += kSliceWords) { tasks_.push_back(Task{&jobs[j], lo, &b}); b.open.fetch_add(1, std::memory_order_relaxed); }
-    cv_.notify_all();
+      for (size_t lo = 0; lo < jobs[j].n; lo += kSliceWords) b.tasks.push_back(Task{&jobs[j], lo});
+    b.open.store((long)b.tasks.size(), std::memory_order_release);
+    if (!b.tasks.empty()) { active_.push_back(&b); cv_.notify_all(); }
   }
   void wait(Batch &b) {
-    for (;;) {   // help with THIS batch's slices until none is queued ...
+    for (;;) {   // help with THIS batch's slices until none is left to hand out ...
       Task t;
       {
         std::lock_guard<std::mutex> lk(m_);
-        size_t k = tasks_.size();
-        while (k > 0 && tasks_[k - 1].batch != &b) --k;
-        if (k == 0) break;
-        t = tasks_[k - 1];
-        tasks_.erase(tasks_.begin() + (long)(k - 1));
+        if (!take(&b, t)) break;
       }
-      run(t);
+      run(t, b);
     }
     std::unique_lock<std::mutex> lk(m_);   // ... then sleep until the workers have handed in the slices they still hold
     done_.wait(lk, [&b] { return b.open.load(std::memory_order_acquire) <= 0; });
   }
 
  private:
-  struct Task { ScanJob *job; size_t lo; Batch *batch; };
   HostPool() = default;
+  // (m_ held) the batch's next slice; a batch that has handed out its last one leaves active_ at once -- it is in there only
+  // while it has slices (active_ holds one entry per context that is scanning right now)
+  bool take(Batch *b, Task &t) {
+    if (b->next >= b->tasks.size()) return false;
+    t = b->tasks[b->next++];
+    if (b->next >= b->tasks.size())
+      for (size_t i = active_.size(); i-- > 0;)
+        if (active_[i] == b) { active_.erase(active_.begin() + (long)i); break; }
+    return true;
+  }
   void start_workers() {
     unsigned n = std::thread::hardware_concurrency();
     n = n <= 2 ? 1 : (n / 2 > 16 ? 16 : n / 2);
@@ -181,11 +205,17 @@ class HostPool {
   void loop() {
     for (;;) {
       Task t;
-      { std::unique_lock<std::mutex> lk(m_); cv_.wait(lk, [this] { return !tasks_.empty(); }); t = tasks_.back(); tasks_.pop_back(); }
-      run(t);
+      Batch *b;
+      {
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return !active_.empty(); });
+        b = active_.back();
+        take(b, t);
+      }
+      run(t, *b);
     }
   }
-  void run(const Task &t) {
+  void run(const Task &t, Batch &b) {
     ScanJob &j = *t.job;
     const size_t hi = t.lo + kSliceWords < j.n ? t.lo + kSliceWords : j.n;
     for (size_t i = t.lo; i < hi && !j.differs.load(std::memory_order_relaxed); i += 4096) {
@@ -194,7 +224,7 @@ class HostPool {
       for (size_t k = i; k < e; ++k) acc |= j.q[k] ^ j.first;
       if (acc) j.differs.store(true, std::memory_order_relaxed);
     }
-    if (t.batch->open.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // the batch's last slice: wake its waiter
+    if (b.open.fetch_sub(1, std::memory_order_acq_rel) == 1) {   // the batch's last slice: wake its waiter (b is not touched again)
       std::lock_guard<std::mutex> lk(m_);
       done_.notify_all();
     }
@@ -202,7 +232,7 @@ class HostPool {
   static std::atomic<HostPool *> g_pool;
   std::mutex m_;
   std::condition_variable cv_, done_;
-  std::vector<Task> tasks_;
+  std::vector<Batch *> active_;
 };
 std::atomic<HostPool *> HostPool::g_pool{nullptr};
 }  // namespace
@@ -295,19 +325,18 @@ std::string default_blob_path(const char *which) {
 
 using namespace rrtmg;
 
-// The caller's struct is copied into one of the library's own: struct_size 0 = the round-3 layout that ended with the
-// outputs (nothing behind them is read: the unit factors stay zero), sizeof = this header; anything else was built against
-// another header and is refused.  Unit factors are for host arrays only.
+// The caller's struct is copied into one of the library's own.  struct_size must be sizeof(Args) of THIS header; anything else
+// -- 0 included: that slot was `reserved0` in two earlier layouts, one that ended with the outputs and one that already carried
+// the unit factors, and the library cannot tell which of them a zero comes from -- was built against another header and is
+// refused, so that no caller ever gets RRTMG_OK with fields dropped or read past its struct.  Unit factors: host arrays only.
 template <class Args, class Impl>
-static int checked_call(rrtmg_ctx *ctx, const Args *a, size_t old_size, const char *what, Impl impl) {
+static int checked_call(rrtmg_ctx *ctx, const Args *a, const char *what, Impl impl) {
   if (!ctx) return RRTMG_ERR_ARG;
   if (!a) return ctx->fail(RRTMG_ERR_ARG, "%s: NULL argument struct", what);
-  if (a->struct_size != 0 && (size_t)a->struct_size != sizeof(Args))
-    return ctx->fail(RRTMG_ERR_ARG, "%s: struct_size %d is not sizeof(%s_args) = %zu of this library (ABI version %d): rebuild the caller against include/rrtmg_hip.h",
+  if ((size_t)a->struct_size != sizeof(Args))
+    return ctx->fail(RRTMG_ERR_ARG, "%s: struct_size %d is not sizeof(%s_args) = %zu of this library (ABI version %d): set it to sizeof of the struct and rebuild the caller against include/rrtmg_hip.h",
                      what, (int)a->struct_size, what, sizeof(Args), RRTMG_HIP_ABI_VERSION);
-  Args own{};
-  memcpy(&own, a, a->struct_size ? sizeof(Args) : old_size);
-  own.struct_size = (int32_t)sizeof(Args);
+  Args own = *a;
   if (own.memspace == 1 && (own.pressure_scale != 0.0 || own.water_path_scale != 0.0 || own.h2o_mul != 0.0 || own.h2o_div != 0.0))
     return ctx->fail(RRTMG_ERR_ARG, "%s: unit factors (pressure_scale, water_path_scale, h2o_mul, h2o_div) apply to host arrays only (memspace 0)", what);
   return impl(ctx, &own);
@@ -329,6 +358,8 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
   if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) { c->chunk_tiles = v; c->chunk_auto = false; } }
+  if (const char *env = getenv("RRTMG_HIP_PIPELINE")) c->pipeline = atoi(env) != 0;
+  if (const char *env = getenv("RRTMG_HIP_MAX_SCRATCH_BYTES")) { const long long v = atoll(env); if (v > 0) c->max_scratch_bytes = (size_t)v; }
   *out = c;
   if (e != hipSuccess || n <= 0)
     return c->fail(RRTMG_ERR_HIP, "no HIP device available (%s): librrtmg_hip has no CPU path", hipGetErrorString(e));
@@ -359,6 +390,11 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
       if (ctx->kiss_ev[w][k]) (void)hipEventDestroy(ctx->kiss_ev[w][k]);
   for (int w = 0; w < 2; ++w)
     if (ctx->sync_ev[w]) (void)hipEventDestroy(ctx->sync_ev[w]);
+  for (int w = 0; w < 2; ++w) {
+    if (ctx->stream_aux[w]) (void)hipStreamDestroy(ctx->stream_aux[w]);
+    for (int k = 0; k < 2; ++k)
+      if (ctx->lane_ev[w][k]) (void)hipEventDestroy(ctx->lane_ev[w][k]);
+  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_lw) (void)hipStreamDestroy(ctx->stream_lw);
   rrtmg::free_sw_desc(ctx);
@@ -380,6 +416,7 @@ int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms) {
   return RRTMG_OK;
 }
 int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which) { return (!ctx || which < 0 || which > 3) ? -1 : ctx->ev_chunks[which]; }
+int rrtmg_hip_chunk_lanes(rrtmg_ctx *ctx, int which) { return (!ctx || which < 0 || which > 1) ? -1 : ctx->lanes_used[which]; }
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
   if (!ctx) return RRTMG_ERR_ARG;
   if (ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -445,8 +482,8 @@ long rrtmg_hip_get_table(rrtmg_ctx *ctx, const char *name, double *out, long cap
   return n;
 }
 
-int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a) { return checked_call(ctx, a, offsetof(rrtmg_sw_args, pressure_scale), "rrtmg_sw", sw_fluxes_impl); }
-int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a) { return checked_call(ctx, a, offsetof(rrtmg_lw_args, pressure_scale), "rrtmg_lw", lw_fluxes_impl); }
+int rrtmg_hip_sw_fluxes(rrtmg_ctx *ctx, const rrtmg_sw_args *a) { return checked_call(ctx, a, "rrtmg_sw", sw_fluxes_impl); }
+int rrtmg_hip_lw_fluxes(rrtmg_ctx *ctx, const rrtmg_lw_args *a) { return checked_call(ctx, a, "rrtmg_lw", lw_fluxes_impl); }
 int rrtmg_hip_abi_version(void) { return RRTMG_HIP_ABI_VERSION; }
 
 int rrtmg_hip_mcica_mask(rrtmg_ctx *ctx, int which, int ncol, int nlay, int icld, int permuteseed, int irng,

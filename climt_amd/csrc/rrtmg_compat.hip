@@ -90,6 +90,7 @@ static void sw_common(rrtmg_sw_args &a, int32_t *ncol, int32_t *nlay, int32_t *i
                       double *swdflx, double *swhr, double *swuflxc, double *swdflxc, double *swhrc, double *bndsolvar,
                       double *indsolvar, double *solcycfrac) {
   a = rrtmg_sw_args{};
+  a.struct_size = (int32_t)sizeof a;
   a.ncol = *ncol; a.nlay = *nlay; a.memspace = 0;
   if (*icld < 0 || *icld > 3) *icld = 2;                       // intent(inout), rrtmg_sw_rad.nomcica.f90:563
   if (*iaer != 0 && *iaer != 6 && *iaer != 10) *iaer = 0;
@@ -202,6 +203,7 @@ static void lw_common(rrtmg_lw_args &a, int32_t *ncol, int32_t *nlay, int32_t *i
                       int32_t *inflglw, int32_t *iceflglw, int32_t *liqflglw, double *tauaer, double *uflx, double *dflx, double *hr,
                       double *uflxc, double *dflxc, double *hrc, double *duflx_dt, double *duflxc_dt) {
   a = rrtmg_lw_args{};
+  a.struct_size = (int32_t)sizeof a;
   a.ncol = *ncol; a.nlay = *nlay; a.memspace = 0;
   if (*icld < 0 || *icld > 3) *icld = 2;
   a.icld = *icld; a.idrv = *idrv; a.inflglw = *inflglw; a.iceflglw = *iceflglw; a.liqflglw = *liqflglw;

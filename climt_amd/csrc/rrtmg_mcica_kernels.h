@@ -10,8 +10,13 @@ namespace rrtmg {
 // The tiles of one column chunk by solve variant, compacted IN TILE ORDER: list[v * cap + i] = the i-th tile (index within the
 // chunk) whose flag is v (0 cloud-free, 1 cloudy), cnt[v] = how many.  One wavefront (ballots + population counts of the lower
 // lanes); launched behind the chunk's preparation kernel, which writes the flags.
+// (64-bit ballots, a 64-thread block: written for the 64-wide wavefronts of gfx950 and nothing else)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "tile_lists_kernel and the solve kernels assume 64-wide wavefronts (the gfx9 family: gfx950)"
+#endif
 static __global__ void __launch_bounds__(64) tile_lists_kernel(const int32_t *tile_cld, int ntile, int32_t *list, int32_t *cnt, int cap) {
   const int lane = threadIdx.x;
+  if (ntile > cap) ntile = cap;   // (the launch sites size the lists for the chunk: never more tiles than list entries)
   int n0 = 0, n1 = 0;
   for (int t0 = 0; t0 < ntile; t0 += 64) {
     const int t = t0 + lane;
@@ -27,6 +32,9 @@ static __global__ void __launch_bounds__(64) tile_lists_kernel(const int32_t *ti
   }
   if (lane == 0) { cnt[0] = n0; cnt[1] = n1; }
 }
+
+// two-lane calls (rrtmg_ctx: chunk pipeline): the preparation kernels' cloudy-tile count goes to the host's hint behind the join
+static __global__ void hint_out_kernel(int32_t *hint_out, int32_t *ncloudy) { *hint_out = *ncloudy; *ncloudy = 0; }
 
 // kissvec sub-columns, one thread per (column, sub-column): grid (nsub, tiles), the sub-column index FASTEST -- the nsub
 // blocks of a tile run back to back and re-read the tile's 64 x nlay cloud fractions from L2 (with tiles fastest the whole

@@ -219,6 +219,55 @@ class RcclComm:
             self.comm = None
 
 
+def comm_selftest(comm, alloc=None, words=128):
+    """First-execution insurance for a communicator at world > 1: every gather mode once on a small pattern -- word i of
+    rank r's block is r * 4096 + i + 0.25, so a block that lands in the wrong slot, arrives partly, or is never written shows
+    up as such -- checked on THIS rank.  -> {"all" | "direct" | "root": "OK" | "FAIL: ..."} (a mode whose call raises reports
+    the exception; nothing propagates: the caller goes on measuring and prints which collective misbehaved).
+
+    `comm` is an RcclComm or anything with its five methods; `alloc(shape)` returns a buffer with .ptr / .download() and an
+    upload from numpy (climt_amd._hip.DeviceArray by default); alloc="host": numpy arrays are handed to the communicator
+    (the gloo communicator of the CPU tests)."""
+    rank, world = comm.rank, comm.world
+    host = alloc == "host"
+    if alloc is None:
+        from . import _hip
+        alloc = _hip.DeviceArray
+
+    def pattern(r):
+        return r * 4096.0 + np.arange(words, dtype=np.float64) + 0.25
+    expect = np.concatenate([pattern(r) for r in range(world)])
+    out = {}
+    for mode in ("all", "direct", "root"):
+        try:
+            send_h, recv_h = pattern(rank), np.full(words * world, -1.0)
+            if host:
+                send, recv = send_h, recv_h
+                sp, rp = send, recv
+            else:
+                send, recv = alloc((words,)), alloc((words * world,))
+                send.upload(send_h); recv.upload(recv_h)
+                sp, rp = send.ptr, recv.ptr
+            {"all": comm.all_gather, "direct": comm.exchange_direct, "root": comm.gather_root}[mode](sp, rp, words)
+            comm.wait()
+            got = recv if host else recv.download()
+            got = np.asarray(got, dtype=np.float64).reshape(world, words)
+            want = expect.reshape(world, words)
+            bad = []
+            for r in range(world):
+                written = mode == "all" or (mode == "direct" and r != rank) or (mode == "root" and rank == 0 and r != 0)
+                if written and not np.array_equal(got[r], want[r]):
+                    k = int(np.flatnonzero(got[r] != want[r])[0])
+                    bad.append("block %d word %d: %r != %r (%d of %d words differ)" % (r, k, float(got[r][k]), float(want[r][k]),
+                                                                                        int((got[r] != want[r]).sum()), words))
+                elif not written and not np.all(got[r] == -1.0):
+                    bad.append("block %d must stay untouched in mode %s and was written" % (r, mode))
+            out[mode] = "OK" if not bad else "FAIL on rank %d: %s" % (rank, "; ".join(bad[:3]))
+        except Exception as e:      # noqa: BLE001 -- the point is to report, per mode, what happened
+            out[mode] = "FAIL on rank %d: %s: %s" % (rank, type(e).__name__, str(e)[:200])
+    return out
+
+
 # ---- the sharded radiation step ----------------------------------------------------------------------------------
 class ShardedRadiation:
     """This rank's block of a column grid, resident on its GPU, and the (double-buffered) gather of the outputs.

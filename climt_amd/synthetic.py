@@ -5,6 +5,8 @@ Everything is produced at the C-ABI boundary of the RRTMG path (after sympl's un
 pressures in hPa (mbar), temperatures in K, volume mixing ratios, water paths in g m^-2, sizes in
 micron, arrays C-contiguous [layer, column] with layer 0 at the surface.
 """
+import os
+
 import numpy as np
 
 SEED = 20260927
@@ -25,6 +27,18 @@ def _qsat(t, p_hpa):
     es = 6.112 * np.exp(17.67 * (t - 273.15) / (t - 29.65))
     es = np.minimum(es, 0.5 * p_hpa)
     return 0.622 * es / (p_hpa - 0.378 * es)
+
+
+_OZONE = None
+
+
+def _ozone_profile(p_pa):
+    global _OZONE
+    from .initialization import not_a_knot_spline
+    if _OZONE is None:
+        tab = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "ozone_profile.npz"))
+        _OZONE = (tab["pressure_Pa"], tab["mole_fraction"])
+    return not_a_knot_spline(p_pa, _OZONE[0], _OZONE[1])
 
 
 def make_columns(ncol, nlay=60, cloudy=False, seed=SEED, nlat=None):
@@ -55,8 +69,9 @@ def make_columns(ncol, nlay=60, cloudy=False, seed=SEED, nlat=None):
     tlev[-1] = tlay[-1]
     q = np.maximum(0.7 * _qsat(tlay, play), 3.0e-6)
     h2o = q * 28.964 / 18.02
-    # ozone: analytic layer peaking near 10 hPa
-    o3 = 0.03e-6 + 8.0e-6 * np.exp(-0.5 * (np.log(play / 8.0) / 1.1) ** 2)
+    # ozone: climt's default profile -- the not-a-knot spline of its 30-point table, evaluated at the layer pressures
+    # (climt/_core/initialization.py:1130-1141); outside the table the end cubics continue, as in climt
+    o3 = _ozone_profile(100.0 * play)
     full = lambda v: np.full((nlay, ncol), v)
     inp = dict(
         play=play, plev=plev, tlay=tlay, tlev=tlev, tsfc=tsfc, h2o=h2o, o3=o3,

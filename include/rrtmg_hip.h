@@ -119,6 +119,10 @@ int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
  * RRTMG_ERR_ARG / 0 launches if that kernel was not launched by the last call. */
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
 int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which);
+/* Column chunks the last call of a spectrum (which = 0 shortwave, 1 longwave) had in flight at once: 1, or 2 for a grid of two
+ * or more chunks (even chunks on the spectrum's stream, odd ones on a second stream of the spectrum, each with its own work
+ * space, so that a chunk's preparation and integration run under the other chunk's solve; RRTMG_HIP_PIPELINE=0: always 1). */
+int rrtmg_hip_chunk_lanes(rrtmg_ctx *ctx, int which);
 
 /* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz,
@@ -200,10 +204,10 @@ typedef struct rrtmg_sw_args {
    * (sub-column, column, layer) order (mcica_subcol_gen_sw.f90:360-367), so a shard skips the other shards' draws and
    * reproduces the unsharded masks bit for bit.  kissvec seeds are per column and ignore it. */
   int32_t shard_col0, shard_ncol;
-  /* sizeof(rrtmg_sw_args) of the header the CALLER was compiled against.  0 = the round-3 layout, which ended with the
-   * outputs: the library then reads nothing behind `swhrc` (no unit factors).  Any other value that is not the library's own
-   * sizeof is refused with RRTMG_ERR_ARG -- a caller built against another header never has fields read past its struct.
-   * (This slot was `reserved0`, documented as zero, in every earlier header: old callers keep working.) */
+  /* sizeof(rrtmg_sw_args) of the header the CALLER was compiled against: REQUIRED.  Any value that is not the library's own
+   * sizeof -- 0 included -- is refused with RRTMG_ERR_ARG: a caller built against another header never has fields dropped
+   * or read past its struct.  (This slot was `reserved0` = 0 in two earlier layouts, with and without the unit factors at
+   * the end; a zero cannot tell them apart, so it is not guessed.) */
   int32_t struct_size;
   double adjes, scon, solcycfrac;
   const double *bndsolvar;   /* [14] (host) or NULL -> ones */
@@ -230,7 +234,7 @@ typedef struct rrtmg_sw_args {
    * caller on the host; 0 = the array is in the unit of the reference already.  play, plev *= pressure_scale (Pa -> mbar:
    * 0.01); cicewp, cliqwp *= water_path_scale (kg m^-2 -> g m^-2: 1000); h2ovmr = h2ovmr * h2o_mul / h2o_div (specific
    * humidity -> volume mixing ratio: 28.964 / 18.02, climt/_core/util.py:86).  One rounding per operation, as numpy.
-   * A struct that was zero-initialised gets none of it.  Read only when struct_size == sizeof(rrtmg_sw_args); with device
+   * A struct that was zero-initialised gets none of it.  With device
    * pointers (memspace 1) a non-zero factor is an error (RRTMG_ERR_ARG): the caller's device arrays are never modified. */
   double pressure_scale, water_path_scale, h2o_mul, h2o_div;
 } rrtmg_sw_args;
@@ -246,7 +250,7 @@ typedef struct rrtmg_lw_args {
   int32_t inflglw, iceflglw, liqflglw;
   int32_t irng, permuteseed;
   int32_t shard_col0, shard_ncol;                    /* see rrtmg_sw_args */
-  int32_t struct_size;                               /* sizeof(rrtmg_lw_args) of the caller's header, or 0 = round-3 layout (see rrtmg_sw_args) */
+  int32_t struct_size;                               /* sizeof(rrtmg_lw_args) of the caller's header: required (see rrtmg_sw_args) */
   const double *play, *plev, *tlay, *tlev, *tsfc;      /* tlev NULL: interpolated on the device from tlay, tsfc, play, plev as
                                                          * climt's get_interface_values does (util.py:89-142) */
   const double *h2ovmr, *o3vmr, *co2vmr, *ch4vmr, *n2ovmr, *o2vmr;

@@ -545,6 +545,25 @@ def reference_lw_class_cases():
               "cloud effect", float(np.abs(exp["diag"]["upwelling_longwave_flux_in_air"][0] - exp["diag"]["upwelling_longwave_flux_in_air_assuming_clear_sky"][0]).max()))
 
 
+def pin_input_hashes():
+    """tests/golden/input_hashes.json: sha256 of the inputs the generator (climt_amd.synthetic) produces for every fixture that
+    stores generator arguments instead of inputs -- re-pinned whenever the fixtures are regenerated (tests/helpers.py checks)."""
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers
+    fn = os.path.join(OUT, "input_hashes.json")
+    names, got = json.load(open(fn)), {}
+    helpers._check_pinned_inputs = lambda name, c: got.__setitem__(name, helpers.input_hash(c))
+    for n in sorted(names):
+        if n.startswith("ref_lwmr_"):
+            helpers.load_lwmr_case(n[len("ref_lwmr_"):])
+        else:
+            helpers.load_ref_case(n[len("ref_"):])
+    assert set(got) == set(names)
+    json.dump(got, open(fn, "w"), indent=1, sort_keys=True)
+    print("input hashes pinned:", sum(got[k] != names[k] for k in got), "changed of", len(got))
+
+
 if __name__ == "__main__":
     if sys.argv[1:] == ["lwclass"]:
         reference_lw_class_cases()
@@ -565,3 +584,4 @@ if __name__ == "__main__":
     for cls in ("TestRRTMGShortwave", "TestRRTMGLongwave"):
         cache_outputs_only(cls, "3d")
     reference_lw_class_cases()
+    pin_input_hashes()

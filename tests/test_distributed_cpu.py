@@ -189,6 +189,22 @@ def _worker3(rank, world, port, q):
                 b = sr.step(mcica=True)
             sr.finish()
             res[(ncol, mode)] = (sr.gathered_host(b), (sr.lo, sr.hi), sr.gather_ingress_bytes())
+    # first-execution insurance of the 8-GPU run (bench.py: comm_selftest): every mode on a small pattern, checked on every
+    # rank -- here over gloo with three ranks -- and a communicator that misroutes one block is NAMED, per mode
+    from climt_amd.distributed import comm_selftest
+    res["selftest"] = comm_selftest(TorchComm(dist, rank, world), alloc="host")
+
+    class Misrouting(TorchComm):
+        def exchange_direct(self, send, recv, count):
+            super().exchange_direct(send, recv, count)
+            a, b = [r for r in range(self.world) if r != self.rank][:2]
+            tmp = recv[a * count:(a + 1) * count].copy()
+            recv[a * count:(a + 1) * count] = recv[b * count:(b + 1) * count]
+            recv[b * count:(b + 1) * count] = tmp
+
+        def gather_root(self, send, recv, count):
+            raise RuntimeError("no route to rank 0")
+    res["selftest_broken"] = comm_selftest(Misrouting(dist, rank, world), alloc="host")
     dist.barrier()
     dist.destroy_process_group()
     q.put((rank, res))
@@ -209,6 +225,10 @@ def test_three_ranks_any_column_count_is_bit_identical():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for rank in range(3):
+        assert res[rank]["selftest"] == {"all": "OK", "direct": "OK", "root": "OK"}, res[rank]["selftest"]
+        broken = res[rank]["selftest_broken"]
+        assert broken["all"] == "OK" and broken["direct"].startswith("FAIL on rank %d: block" % rank) and "no route to rank 0" in broken["root"], broken
     e = EmuContext()
     for ncol, blocks in ((1000, [(0, 384), (384, 704), (704, 1000)]), (100, [(0, 64), (64, 100), (100, 100)])):
         c = make_columns(ncol, 12, cloudy=True, seed=77); c.pop("lat")

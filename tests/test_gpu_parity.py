@@ -405,8 +405,9 @@ def test_sub_column_generator_refuses_an_invalid_icld(gpu_ctx):
 
 
 def test_argument_struct_of_another_header_is_refused(gpu_ctx):
-    """`struct_size` (the former reserved0): 0 = the round-3 layout that ended with the outputs -- the unit factors behind them
-    are NOT read; sizeof = this header; anything else is RRTMG_ERR_ARG.  Unit factors with device pointers are an error."""
+    """`struct_size` (the former reserved0) must be sizeof of this header's struct; anything else -- 0 included: two earlier
+    layouts carried a zero there, with and without the unit factors, and a caller of the second must not have its factors
+    dropped silently -- is RRTMG_ERR_ARG.  Unit factors with device pointers are an error."""
     from climt_amd import _lib
     from climt_amd._lib import RRTMGError
     lib = gpu_ctx.lib
@@ -429,13 +430,14 @@ def test_argument_struct_of_another_header_is_refused(gpu_ctx):
         return out
 
     full = C.sizeof(_lib.SwArgs)
-    for size in (full - 8, full + 32, 7):
+    for size in (full - 8, full + 32, 7, 0):
         with pytest.raises(RRTMGError) as e:
             call(size)
         assert e.value.code == 4 and "struct_size" in str(e.value)
-    # a caller built against the round-3 header: whatever lies behind its struct (here: garbage factors) is not read
-    old = call(0, pressure_scale=123.0, water_path_scale=-5.0, h2o_mul=7.0, h2o_div=3.0)
-    assert all(np.array_equal(old[k], good[k]) for k in good)
+    # a caller built against the round-4 header (reserved0 = 0, unit factors set) is refused, not answered with its factors dropped
+    with pytest.raises(RRTMGError) as e:
+        call(0, pressure_scale=0.01)
+    assert e.value.code == 4 and "struct_size" in str(e.value)
     new = call(full)
     assert all(np.array_equal(new[k], good[k]) for k in good)
     # device pointers + unit factors: refused before anything is enqueued

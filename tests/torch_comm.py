@@ -65,6 +65,9 @@ class _TorchBuf:
     def download(self):
         return self.t.cpu().numpy()
 
+    def upload(self, arr):
+        self.t.copy_(self.t.new_tensor(np.ascontiguousarray(arr, dtype=np.float64).ravel()))
+
 
 class TorchDeviceComm:
     """DEVICE buffers that torch allocated, over torch.distributed (backend nccl = RCCL, or gloo with two ranks on one GPU)."""
