@@ -390,8 +390,7 @@ def main():
             ssw.append(ctx.kernel_ms("sw", cloudy=cld))
             slw.append(ctx.kernel_ms("lw", cloudy=cld))
         n_all = max(1, enq[2])
-        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0],
-                    lanes=(ctx.chunk_lanes("sw"), ctx.chunk_lanes("lw")))
+        return dict(ms=ms, per=per, ksw=ksw, klw=klw, ssw=ssw, slw=slw, enq_sw=enq[0] * 1e3 / n_all, enq=enq[1] * 1e3 / n_all, c=c, brackets=brackets, synced_ms=synced[0])
 
     def pick_steps(ncol, nlay, cld):
         """Steps per bracket: about 1.5 s worth (estimated from the large-grid rates of DESIGN.md 5); brackets repeat to --min-seconds."""
@@ -695,8 +694,6 @@ def main():
                        "columns_per_gpu": N, "levels": L, "parallelism": par,
                        "communicator": (comm_note + comm_kind) if comm_kind else None,
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
-                       "chunk_lanes": {"sw": r["lanes"][0], "lw": r["lanes"][1], "note": "column chunks in flight at once per spectrum (2: a grid of >= 2 chunks "
-                                       "runs its even and odd chunks on two streams of the spectrum, each with its own work space)"} if r.get("lanes") else None,
                        "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
                        "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
                        "host_sync": ("after every step" if (a.serial or a.sync_every_step or (multi and host_wait)) else

@@ -97,7 +97,6 @@ def load_library():
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_kernel_launches.argtypes = [_vp, C.c_int]
-    lib.rrtmg_hip_chunk_lanes.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_copy_blocks.argtypes = [_vp, C.c_int, _vp, C.c_long, C.c_long, _vp, _vp, _vp]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
@@ -213,11 +212,6 @@ class Context:
     def kernel_launches(self, which, cloudy=False):
         """Launches (column chunks) of that solve kernel in the last call; kernel_ms is their sum."""
         return int(self.lib.rrtmg_hip_kernel_launches(self.h, (0 if which == "sw" else 1) + (2 if cloudy else 0)))
-
-    @_locked
-    def chunk_lanes(self, which):
-        """Column chunks the last call of 'sw' | 'lw' had in flight at once (1, or 2: rrtmg_hip_chunk_lanes)."""
-        return int(self.lib.rrtmg_hip_chunk_lanes(self.h, 0 if which == "sw" else 1))
 
     @_locked
     def copy_blocks(self, desc_ptr, nblk, max_rows, max_cols, src, dst, stream=None):

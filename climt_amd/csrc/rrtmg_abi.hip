@@ -69,20 +69,6 @@ int ctx_prepare_device(rrtmg_ctx *ctx) {
   return RRTMG_OK;
 }
 
-int ctx_fork_lane(rrtmg_ctx *ctx, int which, hipStream_t s) {
-  if (!ctx->stream_aux[which]) RRTMG_HIP_CHECK(ctx, hipStreamCreateWithFlags(&ctx->stream_aux[which], hipStreamNonBlocking));
-  for (int k = 0; k < 2; ++k)
-    if (!ctx->lane_ev[which][k]) RRTMG_HIP_CHECK(ctx, hipEventCreateWithFlags(&ctx->lane_ev[which][k], hipEventDisableTiming));
-  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which][0], s));
-  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream_aux[which], ctx->lane_ev[which][0], 0));
-  return RRTMG_OK;
-}
-int ctx_join_lane(rrtmg_ctx *ctx, int which, hipStream_t s) {
-  RRTMG_HIP_CHECK(ctx, hipEventRecord(ctx->lane_ev[which][1], ctx->stream_aux[which]));
-  RRTMG_HIP_CHECK(ctx, hipStreamWaitEvent(s, ctx->lane_ev[which][1], 0));
-  return RRTMG_OK;
-}
-
 int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *herr_dev, int *herr_host) {
   // A destination that is page-locked memory the runtime knows (hipHostMalloc / hipHostRegister: the components' output pool
   // hands such arrays out) takes its copy directly; the others go through the staging buffer.
@@ -358,7 +344,6 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
   if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) { c->chunk_tiles = v; c->chunk_auto = false; } }
-  if (const char *env = getenv("RRTMG_HIP_PIPELINE")) c->pipeline = atoi(env) != 0;
   if (const char *env = getenv("RRTMG_HIP_MAX_SCRATCH_BYTES")) { const long long v = atoll(env); if (v > 0) c->max_scratch_bytes = (size_t)v; }
   *out = c;
   if (e != hipSuccess || n <= 0)
@@ -390,11 +375,6 @@ void rrtmg_hip_destroy(rrtmg_ctx *ctx) {
       if (ctx->kiss_ev[w][k]) (void)hipEventDestroy(ctx->kiss_ev[w][k]);
   for (int w = 0; w < 2; ++w)
     if (ctx->sync_ev[w]) (void)hipEventDestroy(ctx->sync_ev[w]);
-  for (int w = 0; w < 2; ++w) {
-    if (ctx->stream_aux[w]) (void)hipStreamDestroy(ctx->stream_aux[w]);
-    for (int k = 0; k < 2; ++k)
-      if (ctx->lane_ev[w][k]) (void)hipEventDestroy(ctx->lane_ev[w][k]);
-  }
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->stream_lw) (void)hipStreamDestroy(ctx->stream_lw);
   rrtmg::free_sw_desc(ctx);
@@ -416,7 +396,6 @@ int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms) {
   return RRTMG_OK;
 }
 int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which) { return (!ctx || which < 0 || which > 3) ? -1 : ctx->ev_chunks[which]; }
-int rrtmg_hip_chunk_lanes(rrtmg_ctx *ctx, int which) { return (!ctx || which < 0 || which > 1) ? -1 : ctx->lanes_used[which]; }
 int rrtmg_hip_synchronize(rrtmg_ctx *ctx) {
   if (!ctx) return RRTMG_ERR_ARG;
   if (ctx->stream) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

@@ -46,52 +46,40 @@ struct rrtmg_ctx {
   // least a sixteenth): every launch of a solve variant costs whole rounds of workgroups that hold a CU for ~0.8 ms, so a
   // chunk whose 128 tiles split 96 : 32 between the variants pays two rounds for one and a half rounds of work -- large chunks
   // amortise the rounding (131 072 McICA columns, a quarter of the tiles cloud-free: 55.6 ms at 128 tiles per chunk, 42.0 at
-  // 2048; 1 036 800 x 100: 749 -> 572 ms), at the price of work space (bytes_per_tile x tiles x lanes).  Grids of one kind keep
-  // the small chunks, whose rows stay cached (+2..8 % there).
+  // 2048; 1 036 800 x 100: 749 -> 572 ms), at the price of work space (bytes_per_tile x tiles).  Grids of one kind keep the
+  // small chunks, whose rows stay cached (+2..8 % there).
   // Work space: at most max_scratch_bytes per spectrum (RRTMG_HIP_MAX_SCRATCH_BYTES; default an eighth of the device's memory)
-  // and, beyond what the spectrum's scratch buffers already hold, no more than a third of the memory that is free when the
+  // and, beyond what the spectrum's scratch buffer already holds, no more than a third of the memory that is free when the
   // plan is made (a model that has filled the device keeps the small chunks instead of failing).  The plan is made ONCE per
-  // (spectrum, tiles, layers, kind of grid) and kept: no hipMemGetInfo per call, and a stale hint that flips back and forth
-  // re-uses the two plans it has.  INTEGRATION.md states the footprint.
+  // (spectrum, tiles, layers, kind of grid) and kept: no hipMemGetInfo per call, and a hint that flips back and forth re-uses
+  // the two plans it has; ctx->buf never shrinks, so the footprint is the largest plan's (INTEGRATION.md states it).
   size_t max_scratch_bytes = 0;      // 0: device_mem / 8
-  struct ChunkPlan { int ntile = -1, nlay = -1, base = -1, lanes = 0, chunk = 0; };
+  struct ChunkPlan { int ntile = -1, nlay = -1, base = -1, chunk = 0; };
   ChunkPlan plans[2][2];             // [sw|lw][grid of one kind | mixed]
-  // -> tiles per chunk; *lanes = chunks in flight at once (chunk pipeline below): 1 when the grid is one chunk.
-  // chunk_tiles = the chunk a grid of one kind gets (128, or 64 for a deep cloudy grid); scratch0 / scratch1 = the lanes' slabs
-  int plan_chunks(int which, int chunk_tiles, int ntile, int nlay, int hint_cloudy, size_t bytes_per_tile, const char *scratch0, const char *scratch1, int *lanes) {
+  // -> tiles per chunk.  chunk_tiles = the chunk a grid of one kind gets (128, or 64 for a deep cloudy grid)
+  int plan_chunks(int which, int chunk_tiles, int ntile, int nlay, int hint_cloudy, size_t bytes_per_tile, const char *scratch) {
     bool mixed = false;
     if (chunk_auto && hint_cloudy >= 0 && ntile > chunk_tiles) {
       const int fewer = hint_cloudy < ntile - hint_cloudy ? hint_cloudy : ntile - hint_cloudy;
       mixed = 16 * fewer >= ntile;
     }
     ChunkPlan &p = plans[which][mixed ? 1 : 0];
-    if (p.ntile == ntile && p.nlay == nlay && p.base == chunk_tiles) { *lanes = p.lanes; return p.chunk; }
+    if (p.ntile == ntile && p.nlay == nlay && p.base == chunk_tiles) return p.chunk;
     int chunk = chunk_tiles;
     if (mixed) {
-      size_t budget = max_scratch_bytes ? max_scratch_bytes : device_mem / 8, free_b = 0, total_b = 0, have = 0;
-      for (const char *nm : {scratch0, scratch1}) { const auto it = bufs.find(nm); if (it != bufs.end()) have += it->second.cap; }
+      size_t budget = max_scratch_bytes ? max_scratch_bytes : device_mem / 8, free_b = 0, total_b = 0;
+      const auto it = bufs.find(scratch);
+      const size_t have = it == bufs.end() ? 0 : it->second.cap;
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) free_b = 0;
       const size_t room = have > free_b / 3 ? have : free_b / 3;
       if (room < budget) budget = room;
-      const size_t per_tile = bytes_per_tile ? bytes_per_tile : 1;
-      auto tiles_for = [&](int nl) { const long c = (long)(budget / nl / per_tile) / 128 * 128; return c > 2048 ? 2048L : c; };
-      long cap = tiles_for(1);
-      if (cap < ntile && pipeline) cap = tiles_for(2);   // more than one chunk: the two lanes share the budget
+      long cap = (long)(budget / (bytes_per_tile ? bytes_per_tile : 1)) / 128 * 128;
+      if (cap > 2048) cap = 2048;
       if (cap > chunk_tiles) chunk = (int)cap;
     }
     p.ntile = ntile; p.nlay = nlay; p.base = chunk_tiles; p.chunk = chunk;
-    p.lanes = (pipeline && ntile > chunk) ? 2 : 1;
-    *lanes = p.lanes;
     return chunk;
   }
-  // Chunk pipeline: a grid of two or more column chunks runs its even chunks on the spectrum's stream and its odd ones on a
-  // second stream of the spectrum (forked behind the whole-grid kernels of the call, joined before the call's end), each lane
-  // with its own scratch slab, partial planes and tile lists -- chunk i+1's preparation and integration (HBM-bound, 15 % of a
-  // chunk's time) and the head of its solve run in the CUs the tail of chunk i's solve leaves idle.  RRTMG_HIP_PIPELINE=0: one lane.
-  bool pipeline = true;
-  hipStream_t stream_aux[2] = {nullptr, nullptr};     // [sw|lw] second lane
-  hipEvent_t lane_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [sw|lw][fork|join]
-  int lanes_used[2] = {1, 1};        // lanes of the last call [sw|lw] (rrtmg_hip_chunk_lanes)
   // What the PREVIOUS call of a spectrum [sw|lw] found -- tiles, layers, tiles with a cloud -- for sizing and ordering the
   // launches of the next one.  The count is left in page-locked memory by the call's last kernel (which also clears the counter) and read
   // WITHOUT waiting when the next call is enqueued (stale, or missing, in a loop that runs ahead of the GPU): a hint.  Every
@@ -200,9 +188,6 @@ int copy_out(rrtmg_ctx *ctx, hipStream_t s, const OutCopy *o, int count, int *he
 namespace rrtmg {
 const char *status_message(int code);
 int ctx_prepare_device(rrtmg_ctx *ctx);   // hipSetDevice + lazy stream / error-flag creation
-// chunk pipeline: the spectrum's second lane (stream_aux[which]) waits for what is enqueued on s so far / s waits for the lane
-int ctx_fork_lane(rrtmg_ctx *ctx, int which, hipStream_t s);
-int ctx_join_lane(rrtmg_ctx *ctx, int which, hipStream_t s);
 std::string default_blob_path(const char *which);
 void free_sw_desc(rrtmg_ctx *ctx);
 void free_lw_desc(rrtmg_ctx *ctx);

@@ -258,17 +258,13 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const int hint_cloudy = (ctx->hint[1].ntile == ntile && ctx->hint[1].nlay == L) ? ctx->hint[1].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
-  int lanes = 1;   // chunks in flight at once (rrtmg_ctx: chunk pipeline)
-  chunk_tiles = ctx->plan_chunks(1, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kLwNGpt * LF_N * L * 64 * sizeof(double), "lw.w.scratch", "lw.w.scratch1", &lanes);
+  chunk_tiles = ctx->plan_chunks(1, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kLwNGpt * LF_N * L * 64 * sizeof(double), "lw.w.scratch");
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
-  d.tcap = ctile;
-  struct Lane { hipStream_t s; int32_t *tlist; double *scratch, *part; } lane[2] = {};
-  for (int k = 0; k < lanes; ++k) {   // each lane: its own tile lists, scratch slab and partial planes
-    lane[k].tlist = (int32_t *)ctx->buf(k ? "lw.w.tilelist1" : "lw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
-    if (!lane[k].tlist) ok = false;
-    lane[k].scratch = wd(k ? "scratch1" : "scratch", (size_t)ctile * kLwNGpt * LF_N * L * 64);
-    lane[k].part = wd(k ? "part1" : "part", (size_t)T.nitem * nk * (L + 1) * ctile * 64);
-  }
+  int32_t *tlist = (int32_t *)ctx->buf("lw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
+  if (!tlist) ok = false;
+  d.tcap = ctile; d.tlist = tlist; d.tcnt = tlist ? tlist + 2 * d.tcap : nullptr;
+  d.scratch = wd("scratch", (size_t)ctile * kLwNGpt * LF_N * L * 64);
+  d.part = wd("part", (size_t)T.nitem * nk * (L + 1) * ctile * 64);
   if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
   if (d.idrv && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
   if (a->memspace == 1) {
@@ -321,48 +317,33 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
     }
   }
   // preparation, solve and band integration, one column chunk at a time (see sw_fluxes_impl)
-  lane[0].s = s;
-  if (lanes == 2) {   // the second lane starts behind everything enqueued so far (inputs, masks, interface temperatures)
-    rc = ctx_fork_lane(ctx, 1, s);
-    if (rc) return rc;
-    lane[1].s = ctx->stream_aux[1];
-  }
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
-    const int ci = t0 / ctile;
-    const Lane &ln = lane[ci % lanes];
-    hipStream_t cs = ln.s;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
-    d.tlist = ln.tlist; d.tcnt = ln.tlist + 2 * d.tcap; d.scratch = ln.scratch; d.part = ln.part;
-    hipLaunchKernelGGL(lw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), cs, d, T,
+    hipLaunchKernelGGL(lw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)keep_layers * 3 * 64 * sizeof(double), s, d, T,
                        clouds && !d.mcica ? 1 : 0, maxrand ? 1 : 0, keep_layers, t0);
-    if (clouds && d.mcica) hipLaunchKernelGGL(lw_cloudmc_kernel, dim3(nt, L), blk, 0, cs, d, T, t0);
-    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, cs, d.tile_cld + t0, nt, ln.tlist, ln.tlist + 2 * d.tcap, d.tcap);
+    if (clouds && d.mcica) hipLaunchKernelGGL(lw_cloudmc_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
+    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, s, d.tile_cld + t0, nt, tlist, tlist + 2 * d.tcap, d.tcap);
     const dim3 lwwg(64 * kLwWgWaves);
     const int lwgrid = (nt + kLwTileGroup - 1) / kLwTileGroup * kLwGroupBlocks * T.nitem;
+    const int ci = t0 / ctile;
     auto clear_variant = [&]() {
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), cs);
-      hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, cs, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), cs);
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 0), s);
+      hipLaunchKernelGGL((lw_solve_all_kernel<false, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(1, ci, 1), s);
     };
     auto cloudy_variant = [&]() {
-      (void)hipEventRecord(ctx->chunk_event(3, ci, 0), cs);
-      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, cs, d, T, t0, nt);
-      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, cs, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(3, ci, 1), cs);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 0), s);
+      if (maxrand) hipLaunchKernelGGL((lw_solve_all_kernel<true, true>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      else hipLaunchKernelGGL((lw_solve_all_kernel<true, false>), dim3(lwgrid), lwwg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
     };
     // the variant expected to find nothing goes first (see sw_fluxes_impl)
     if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
     else { clear_variant(); if (clouds) cloudy_variant(); }
-    d.hint_out = (lanes == 1 && t0 + ctile >= ntile) ? (int32_t *)&ctx->hint[1].ncloudy : nullptr;
-    hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, cs, d, T, t0);
+    d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[1].ncloudy : nullptr;
+    hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
-  if (lanes == 2) {
-    rc = ctx_join_lane(ctx, 1, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(hint_out_kernel, dim3(1), dim3(1), 0, s, (int32_t *)&ctx->hint[1].ncloudy, d.ncloudy);
-  }
-  ctx->lanes_used[1] = lanes;
   ctx->hint[1].ntile = ntile; ctx->hint[1].nlay = L;
   ctx->ev_chunks[1] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[3] = clouds ? ctx->ev_chunks[1] : 0;
   RRTMG_HIP_CHECK(ctx, hipGetLastError());

@@ -33,9 +33,6 @@ static __global__ void __launch_bounds__(64) tile_lists_kernel(const int32_t *ti
   if (lane == 0) { cnt[0] = n0; cnt[1] = n1; }
 }
 
-// two-lane calls (rrtmg_ctx: chunk pipeline): the preparation kernels' cloudy-tile count goes to the host's hint behind the join
-static __global__ void hint_out_kernel(int32_t *hint_out, int32_t *ncloudy) { *hint_out = *ncloudy; *ncloudy = 0; }
-
 // kissvec sub-columns, one thread per (column, sub-column): grid (nsub, tiles), the sub-column index FASTEST -- the nsub
 // blocks of a tile run back to back and re-read the tile's 64 x nlay cloud fractions from L2 (with tiles fastest the whole
 // cldfr array streamed through once per sub-column: 8 GB per launch at 131072 columns, where it no longer fits the L2s).

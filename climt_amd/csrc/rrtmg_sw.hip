@@ -364,17 +364,13 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   const int hint_cloudy = (ctx->hint[0].ntile == ntile && ctx->hint[0].nlay == L) ? ctx->hint[0].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
-  int lanes = 1;   // chunks in flight at once (rrtmg_ctx: chunk pipeline)
-  chunk_tiles = ctx->plan_chunks(0, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double), "sw.w.scratch", "sw.w.scratch1", &lanes);
+  chunk_tiles = ctx->plan_chunks(0, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double), "sw.w.scratch");
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
-  d.tcap = ctile;
-  struct Lane { hipStream_t s; int32_t *tlist; double *scratch, *part; } lane[2] = {};
-  for (int k = 0; k < lanes; ++k) {   // each lane: its own tile lists, scratch slab and partial planes
-    lane[k].tlist = (int32_t *)ctx->buf(k ? "sw.w.tilelist1" : "sw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
-    if (!lane[k].tlist) ok = false;
-    lane[k].scratch = wd(k ? "scratch1" : "scratch", (size_t)ctile * kSwNGpt * F_NTOT * L * 64);
-    lane[k].part = wd(k ? "part1" : "part", (size_t)kSwNSlot * 4 * (L + 1) * ctile * 64);
-  }
+  int32_t *tlist = (int32_t *)ctx->buf("sw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
+  if (!tlist) ok = false;
+  d.tcap = ctile; d.tlist = tlist; d.tcnt = tlist ? tlist + 2 * d.tcap : nullptr;
+  d.scratch = wd("scratch", (size_t)ctile * kSwNGpt * F_NTOT * L * 64);
+  d.part = wd("part", (size_t)kSwNSlot * 4 * (L + 1) * ctile * 64);
   if (!svar_col.empty()) {   // per-column solar-variability multipliers (rare: facular/sunspot amplitudes != 1)
     double *p = wd("svarcol", svar_col.size());
     if (!ok) return ctx->status;
@@ -422,47 +418,35 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   // preparation, solve and spectral integration, one column chunk at a time: the chunk's prep rows (58 MB at 8192 columns x
   // 60 layers) are read by its 32 work items while still in the L2s / the Infinity Cache, not streamed back from HBM after
   // the preparation of the whole grid (every solve launch of every chunk has its own event pair)
-  lane[0].s = s;
-  if (lanes == 2) {   // the second lane starts behind everything enqueued so far (inputs, masks, aerosol mixing)
-    rc = ctx_fork_lane(ctx, 0, s);
-    if (rc) return rc;
-    lane[1].s = ctx->stream_aux[0];
-  }
+  // (Two chunks in flight at once -- even and odd chunks on two streams of the spectrum, each with its own work space -- were
+  // built and measured in round 6: 131 072 clear-sky columns 23.2 -> 24.1-24.5 ms, config-5 shard 72.9-73.7 -> 74.1-74.9,
+  // config-4 shard 5.83-5.94 -> 5.79-5.89: the other spectrum's solve already runs over a chunk's preparation and
+  // integration, and two solves of one spectrum sharing the CUs take 1.7 x as long each.  docs/EXPERIMENTS.md E.)
   for (int t0 = 0; t0 < ntile; t0 += ctile) {
     const int nt = ntile - t0 < ctile ? ntile - t0 : ctile;
-    const int ci = t0 / ctile;
-    const Lane &ln = lane[ci % lanes];
-    hipStream_t cs = ln.s;
     d.col0 = t0 * 64; d.pcols = ctile * 64;
-    d.tlist = ln.tlist; d.tcnt = ln.tlist + 2 * d.tcap; d.scratch = ln.scratch; d.part = ln.part;
-    hipLaunchKernelGGL(sw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), cs, d, T, clouds && !d.mcica ? 1 : 0, t0);
-    if (clouds && d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, dim3(nt, L), blk, 0, cs, d, T, t0);
-    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, cs, d.tile_cld + t0, nt, ln.tlist, ln.tlist + 2 * d.tcap, d.tcap);
+    hipLaunchKernelGGL(sw_prep_fused_kernel, dim3(nt), dim3(64 * kPrepWaves), (size_t)L * 64 * sizeof(int), s, d, T, clouds && !d.mcica ? 1 : 0, t0);
+    if (clouds && d.mcica) hipLaunchKernelGGL(sw_cloud_kernel, dim3(nt, L), blk, 0, s, d, T, t0);
+    hipLaunchKernelGGL(tile_lists_kernel, dim3(1), blk, 0, s, d.tile_cld + t0, nt, tlist, tlist + 2 * d.tcap, d.tcap);
     const int ngrp = (nt + kSwWgWaves - 1) / kSwWgWaves;
     const dim3 wg(64 * kSwWgWaves);
+    const int ci = t0 / ctile;
     auto clear_variant = [&]() {
-      (void)hipEventRecord(ctx->chunk_event(0, ci, 0), cs);
-      hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem), wg, 0, cs, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(0, ci, 1), cs);
+      (void)hipEventRecord(ctx->chunk_event(0, ci, 0), s);
+      hipLaunchKernelGGL(sw_solve_all_kernel<false>, dim3(ngrp * T.nitem), wg, 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(0, ci, 1), s);
     };
     auto cloudy_variant = [&]() {
-      (void)hipEventRecord(ctx->chunk_event(2, ci, 0), cs);
-      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem), dim3(64 * kC4Waves), 0, cs, d, T, t0, nt);
-      (void)hipEventRecord(ctx->chunk_event(2, ci, 1), cs);
+      (void)hipEventRecord(ctx->chunk_event(2, ci, 0), s);
+      hipLaunchKernelGGL(sw_solve_cloudy_kernel, dim3((nt + kC4Waves - 1) / kC4Waves * T.nitem), dim3(64 * kC4Waves), 0, s, d, T, t0, nt);
+      (void)hipEventRecord(ctx->chunk_event(2, ci, 1), s);
     };
     // the variant expected to find nothing goes first (order is speed only: each tile belongs to exactly one of them)
     if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
     else { clear_variant(); if (clouds) cloudy_variant(); }
-    // (one lane: the call's last launch hands the cloudy-tile count over; two lanes: a launch of its own behind the join)
-    d.hint_out = (lanes == 1 && t0 + ctile >= ntile) ? (int32_t *)&ctx->hint[0].ncloudy : nullptr;
-    hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, cs, d, T, t0);
+    d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[0].ncloudy : nullptr;
+    hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);
   }
-  if (lanes == 2) {
-    rc = ctx_join_lane(ctx, 0, s);
-    if (rc) return rc;
-    hipLaunchKernelGGL(hint_out_kernel, dim3(1), dim3(1), 0, s, (int32_t *)&ctx->hint[0].ncloudy, d.ncloudy);
-  }
-  ctx->lanes_used[0] = lanes;
   ctx->hint[0].ntile = ntile; ctx->hint[0].nlay = L;
   ctx->ev_chunks[0] = (ntile + ctile - 1) / ctile; ctx->ev_chunks[2] = clouds ? ctx->ev_chunks[0] : 0;
   RRTMG_HIP_CHECK(ctx, hipGetLastError());

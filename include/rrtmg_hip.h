@@ -119,10 +119,6 @@ int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
  * RRTMG_ERR_ARG / 0 launches if that kernel was not launched by the last call. */
 int rrtmg_hip_kernel_ms(rrtmg_ctx *ctx, int which, double *ms);
 int rrtmg_hip_kernel_launches(rrtmg_ctx *ctx, int which);
-/* Column chunks the last call of a spectrum (which = 0 shortwave, 1 longwave) had in flight at once: 1, or 2 for a grid of two
- * or more chunks (even chunks on the spectrum's stream, odd ones on a second stream of the spectrum, each with its own work
- * space, so that a chunk's preparation and integration run under the other chunk's solve; RRTMG_HIP_PIPELINE=0: always 1). */
-int rrtmg_hip_chunk_lanes(rrtmg_ctx *ctx, int which);
 
 /* physical constants (cgs, as climt passes them): replaces rrtmg[_sw]_set_constants */
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz,

@@ -192,7 +192,10 @@ def test_against_live_oracle_at_larger_size(gpu_ctx, ncol, nlay):
         from oracle.port_driver import PortLW, PortSW
         require_reference_oracle("port")
         esw, elw = PortSW().fluxes(c, mcica=True), PortLW().fluxes(c, mcica=True)
-    _check(gpu_ctx.sw_fluxes(c, mcica=True), esw)
+    # shortwave: 2048 x 112 x 60 evaluations of reftra, a few of them near its ill-conditioned spot k * mu0 = 1, where the device's
+    # one-reciprocal form and the reference differ by up to ~3e-8 W m^-2 (tools/fuzz_parity.py: worst 3.1e-8 in 380
+    # draws, otherwise <= 7.2e-9; this sample: 6.8e-9 with climt's ozone profile): 5e-8 here, TIGHT on every committed fixture
+    _check(gpu_ctx.sw_fluxes(c, mcica=True), esw, tight=5.0e-8)
     _check(gpu_ctx.lw_fluxes(c, mcica=True), elw)
 
 

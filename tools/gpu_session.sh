@@ -52,6 +52,24 @@ except Exception as e:
     print('$lib $mode FAILED', e)" | tee -a $O/${R}_ab.txt
         done
       done ;;
+    absize:*)
+      # as ab:, on the large grids: AB_SIZES = ';'-separated bench.py argument sets (default: configs 4 and 5 shards, 131 072 clear-sky and McICA columns)
+      IFS=';' read -ra SPECS <<< "${AB_SIZES:---config 4;--config 5;--columns 131072;--columns 131072 --cloudy}"
+      for rep in 1 2; do
+      for spec in "${SPECS[@]}"; do
+        for ent in $(echo ${sec#absize:} | tr , ' '); do
+          lib=${ent%%+*}; envs=""; [ "$ent" != "$lib" ] && envs=$(echo ${ent#*+} | tr + ' ')
+          L=$PWD/climt_amd/_lib/ab/$lib; [ $lib = product ] && L=$PWD/climt_amd/_lib/librrtmg_hip.so
+          env $envs RRTMG_HIP_LIB=$L timeout 300 python bench.py --no-cpu-baseline --no-extra --no-mcica --min-seconds 1.5 $spec 2>&1 | tail -1 | python -c "
+import json,sys
+try:
+    j=json.loads(sys.stdin.read()); r=j['roofline']
+    print('%-44s %-28s %9d col/s %8.3f ms  sw %.3f lw %.3f per launch' % ('$ent', '$spec', j['value'], j['ms_per_step'], r['sw_solve_ms'], r['lw_solve_ms']))
+except Exception as e:
+    print('$ent $spec FAILED', e)" | tee -a $O/${R}_absize.txt
+        done
+      done
+      done ;;
     phases)
       # the diagnostic build with phase timers in the longwave sweeps (climt_amd/_lib/lib_profile.so: RRTMG_HIP_BUILD_FLAGS=-DRRTMG_PROFILE RRTMG_HIP_BUILD_OUT=.../lib_profile.so python climt_amd/build.py --force)
       for mode in "" "--cloudy"; do
