@@ -272,6 +272,18 @@ def _opt_emis(c, rng):
     c["emis"] = np.ascontiguousarray(rng.uniform(0.90, 0.99, (16, ncol)))
 
 
+def _opt_abundant(c, rng):
+    """CO2 and N2O well above the reference profiles in most columns: taumol's "too abundant" column adjustments (bands 3, 6, 7,
+    8, 9, 13: adjfac = a + (rat - a)**e once rat exceeds 1.5 / 3.0, rrtmg_lw_taumol.f90:704-720 etc.) take their pow() branch
+    in some layers and columns and not in others (the first columns keep the defaults)."""
+    nlay, ncol = c["play"].shape
+    fco2 = np.concatenate([[1.0, 1.0], rng.uniform(1.0, 8.0, ncol - 2)])
+    fn2o = np.concatenate([[1.0, 1.0], rng.uniform(1.0, 5.0, ncol - 2)])
+    c["co2"] = np.ascontiguousarray(c["co2"] * fco2[None, :] * rng.uniform(0.8, 1.2, (nlay, ncol)))
+    c["n2o"] = np.ascontiguousarray(c["n2o"] * fn2o[None, :] * rng.uniform(0.8, 1.2, (nlay, ncol)))
+    _opt_emis(c, rng)
+
+
 def option_cases():
     """name -> (spectrum, mcica, inputs): every non-default option of the path with its own seeded inputs."""
     cases = {}
@@ -302,13 +314,15 @@ def option_cases():
     add("lw_inflag0_maxrand", "lw", False, 36, lambda c, r: _opt_inflag0(c, r, 16), icld=2)
     add("lw_inflag0_mcica", "lw", True, 37, lambda c, r: (_opt_inflag0(c, r, 16), _opt_emis(c, r)), icld=1)
     add("lw_inflag1_random", "lw", False, 38, lambda c, r: _opt_emis(c, r), icld=1, inflg=1)
+    add("lw_abundant_clear", "lw", False, 81, _opt_abundant, icld=0)
+    add("lw_abundant_mcica", "lw", True, 82, _opt_abundant, icld=2)
     for ice, liq in ((0, 0), (0, 1), (1, 0), (2, 1), (3, 1), (2, 0), (3, 0)):
         add("lw_ice%d_liq%d_random" % (ice, liq), "lw", False, 40 + 4 * ice + liq, lambda c, r, i=ice, q=liq: (_opt_sizes(c, r, i, q), _opt_emis(c, r)), icld=1)
         add("lw_ice%d_liq%d_mcica" % (ice, liq), "lw", True, 60 + 4 * ice + liq, lambda c, r, i=ice, q=liq: _opt_sizes(c, r, i, q), icld=2)
     return cases
 
 
-def reference_option_cases():
+def reference_option_cases(only=None):
     """ref_opt_<name>.npz: inputs stored IN the fixture (self-contained), outputs of the reference Fortran."""
     from oracle.ref_driver import RefLW, RefSW
     from tools.pack_tables import read_blob
@@ -318,6 +332,8 @@ def reference_option_cases():
     lw = RefLW()
     lw.init(fill_tables=lambda r: fill_reference_from_blob(r, blob))
     for name, (spectrum, mcica, c) in option_cases().items():
+        if only and not any(o in name for o in only):
+            continue
         save = {"in/" + k: v for k, v in c.items() if isinstance(v, np.ndarray)}
         save.update({"flag/" + k: np.array(v) for k, v in c.items() if not isinstance(v, np.ndarray)})
         save["flag/_mcica"] = np.array(int(mcica))
@@ -567,6 +583,9 @@ def pin_input_hashes():
 if __name__ == "__main__":
     if sys.argv[1:] == ["lwclass"]:
         reference_lw_class_cases()
+        sys.exit(0)
+    if sys.argv[1:2] == ["options"]:      # options <substring> ...: only those option fixtures
+        reference_option_cases(only=sys.argv[2:])
         sys.exit(0)
     n = 0
     for cls in ("TestRRTMGLongwave", "TestRRTMGLongwaveMCICA", "TestRRTMGLongwaveWithClouds",
