@@ -61,7 +61,11 @@ CONSTANTS = dict(pi=np.pi, grav=9.80665, planck=6.62607004e-27, boltz=1.38064852
                  avogad=6.022140857e23, alosmt=2.6867774e19, gascon=8.3144598e7, sbcnst=5.670367e-12, secdy=86400.0)
 CPDAIR = 1004.64
 HBM_PEAK = 8.0e12
-HBM_SUSTAINED = 6.3e12     # what a streaming kernel achieves on this part (MI355X_MICROARCH.md; the flux kernels reach 4.3-4.5e12)
+HBM_SUSTAINED = 6.3e12     # what a READ-streaming kernel achieves on this part (MI355X_MICROARCH.md; tools/micro/hbm_stream: 6.5-7.2e12)
+# ... and what it sustains for the step's own mix -- the scratch slabs and partial planes are written once and read once, 45 % of the
+# step's HBM-side bytes are writes: copy kernels and the slab pattern itself (thousands of wavefronts each writing, then reading
+# back, its own region in 1 KB runs, non-temporal) reach 4.6-5.4e12 read + written (profiles/r06_hbm_stream.txt)
+HBM_SUSTAINED_MIXED = 5.3e12
 # vector FP64: AMD's MI355X specification (78.6 TFLOP/s) = 256 CUs x 4 SIMDs x 16 FP64 FMA lanes x 2 flop x 2.4 GHz -- the CU count
 # and clock are in MI355X_MICROARCH.md, the per-SIMD FP64 rate (a wavefront's FP64 FMA issues over 4 cycles) is AMD's CDNA figure
 FP64_PEAK = 78.6e12
@@ -665,6 +669,9 @@ def main():
                     "step_traffic": step_traffic,
                     "step_traffic_over_algorithmic": (step_traffic / (step_bytes * N)) if step_traffic else None,
                     "step_hbm_side_frac": (step_traffic / (ms * 1e-3) / HBM_SUSTAINED) if step_traffic else None,
+                    "step_hbm_side_frac_of_mixed_rate": (step_traffic / (ms * 1e-3) / HBM_SUSTAINED_MIXED) if step_traffic else None,
+                    "hbm_rates_measured": {"read_streaming": HBM_SUSTAINED, "write_read_mix_of_the_step": HBM_SUSTAINED_MIXED,
+                                           "source": "profiles/r06_hbm_stream.txt (tools/micro/hbm_stream.hip): reads 6.5-7.2e12 B/s, copy and write-then-read-back slab pattern 4.6-5.4e12"},
                     "step_hbm_side_frac_of_peak": (step_traffic / (ms * 1e-3) / HBM_PEAK) if step_traffic else None,
                     "fp64_flops_per_launch": flops, "fp64_frac": (flops / (kms * 1e-3) / FP64_PEAK) if flops else None,
                     "fp64_frac_serial": (flops / (kms_serial * 1e-3) / FP64_PEAK) if flops else None,
@@ -677,7 +684,8 @@ def main():
                             "limiter = what actually holds the kernel; issue_frac = VALU issue time per SIMD / kernel_ms (kernels[].issue_frac_alone for both kernels), "
                             "step_issue_frac = the two solve kernels' VALU issue time per SIMD summed / ms_per_step: the fractions that steer work here; "
                             "step_frac is quoted on the contract's bytes, step_frac_on_shipped_bytes on the arrays this run really hands over.  traffic / step_traffic = measured HBM-side bytes (2 x FETCH_SIZE + WRITE_SIZE, PMC "
-                            "passes of this command committed under profiles/); step_hbm_side_frac = step_traffic / ms_per_step / 6.3 TB/s"}
+                            "passes of this command committed under profiles/); step_hbm_side_frac = step_traffic / ms_per_step / 6.3 TB/s (a read stream's rate), "
+                            "step_hbm_side_frac_of_mixed_rate = the same / 5.3 TB/s (what copy kernels and the slab's own write-then-read pattern reach on this part)"}
         launches = max(1, ctx.kernel_launches("sw", cloudy=cloudy))      # column chunks per call: one launch of each solve kernel per chunk
         roofline = roofline_block(N, L, cloudy, r, ms, launches)
         par = "columns sharded x%d" % world
