@@ -471,7 +471,7 @@ def main():
         if comm.kind != "none" and not a.no_comm_selftest:
             from climt_amd.distributed import comm_selftest
             try:
-                mine = comm_selftest(comm, alloc=alloc)
+                mine = comm_selftest(comm, alloc=alloc, check_untouched=comm.kind == "rccl")
             except Exception as e:      # pragma: no cover
                 mine = {"all": "FAIL on rank %d: %r" % (rank, e)}
             every = [None] * world

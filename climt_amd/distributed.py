@@ -219,7 +219,7 @@ class RcclComm:
             self.comm = None
 
 
-def comm_selftest(comm, alloc=None, words=128):
+def comm_selftest(comm, alloc=None, words=128, check_untouched=True):
     """First-execution insurance for a communicator at world > 1: every gather mode once on a small pattern -- word i of
     rank r's block is r * 4096 + i + 0.25, so a block that lands in the wrong slot, arrives partly, or is never written shows
     up as such -- checked on THIS rank.  -> {"all" | "direct" | "root": "OK" | "FAIL: ..."} (a mode whose call raises reports
@@ -227,7 +227,8 @@ def comm_selftest(comm, alloc=None, words=128):
 
     `comm` is an RcclComm or anything with its five methods; `alloc(shape)` returns a buffer with .ptr / .download() and an
     upload from numpy (climt_amd._hip.DeviceArray by default); alloc="host": numpy arrays are handed to the communicator
-    (the gloo communicator of the CPU tests)."""
+    (the gloo communicator of the CPU tests).  check_untouched=False: blocks a mode has no business writing are not looked at
+    (the testing communicator over torch.distributed gathers the own block too, which readers of `direct` never look at)."""
     rank, world = comm.rank, comm.world
     host = alloc == "host"
     if alloc is None:
@@ -260,7 +261,7 @@ def comm_selftest(comm, alloc=None, words=128):
                     k = int(np.flatnonzero(got[r] != want[r])[0])
                     bad.append("block %d word %d: %r != %r (%d of %d words differ)" % (r, k, float(got[r][k]), float(want[r][k]),
                                                                                         int((got[r] != want[r]).sum()), words))
-                elif not written and not np.all(got[r] == -1.0):
+                elif check_untouched and not written and not np.all(got[r] == -1.0):
                     bad.append("block %d must stay untouched in mode %s and was written" % (r, mode))
             out[mode] = "OK" if not bad else "FAIL on rank %d: %s" % (rank, "; ".join(bad[:3]))
         except Exception as e:      # noqa: BLE001 -- the point is to report, per mode, what happened
