@@ -176,7 +176,6 @@ except ImportError:
                 plan = plans[sig] = self._plan(state)
             steps, self._dim_lengths, self._wild_names, self._wild_shape = plan
             # components whose library applies unit factors on the device name the inputs it may do that for
-            # (climt_amd/rrtmg: pressures, cloud water paths): those go through unconverted, the factor beside them
             # (climt_amd/rrtmg: pressures, cloud water paths): those go through unconverted under the key name + "@raw", the
             # factor beside them in "_unit_factors" -- raw[name] itself is then ABSENT, so that whatever reads state[name] on the
             # host always gets the unit input_properties declares, or a KeyError, never a silently different unit.  Components
