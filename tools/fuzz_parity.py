@@ -36,6 +36,10 @@ def main():
                  inflg=2, iceflg=int(rng.integers(1, 4)), liqflg=1, irng=int(rng.integers(0, 2)), permuteseed=int(rng.integers(1, 1024)), idrv=int(rng.integers(0, 2)))
         c["coszen"] = np.clip(c["coszen"] * rng.uniform(-0.2, 1.2, ncol), -0.1, 1.0)      # night columns too
         c["emis"] = rng.uniform(0.85, 1.0, (16, ncol))
+        gases = int(rng.integers(0, 3))
+        if gases == 2:    # trace gases far from the reference profiles: taumol's "too abundant" column adjustments (lw_adjcol's pow branch)
+            c["co2"] = c["co2"] * rng.uniform(0.3, 9.0, ncol)[None, :]; c["n2o"] = c["n2o"] * rng.uniform(0.3, 6.0, ncol)[None, :]
+            c["ch4"] = c["ch4"] * rng.uniform(0.3, 4.0, ncol)[None, :]; c["o3"] = c["o3"] * rng.uniform(0.3, 3.0, (nlay, ncol))
         opt = rng.integers(0, 4)
         if opt == 1:      # user aerosols
             c["tauaer"] = rng.uniform(0, 0.05, (14, nlay, ncol)); c["ssaaer"] = rng.uniform(0.7, 1.0, (14, nlay, ncol)); c["asmaer"] = rng.uniform(0.2, 0.8, (14, nlay, ncol))
@@ -62,8 +66,8 @@ def main():
         dsw = max(maxdiff(gsw[k], rsw[k]) for k in rsw); dlw = max(maxdiff(glw[k], rlw[k]) for k in rlw)
         worst["sw"], worst["lw"] = max(worst["sw"], dsw), max(worst["lw"], dlw)
         flag = "" if dsw < 1e-6 and dlw < 1e-7 else "   <<<<<<"
-        print("%3d %s ncol %4d nlay %3d mcica %d rng %d icld %d opt %d ice %d/%d liq %d idrv %d  |d| sw %.2e lw %.2e%s" % (
-            it, kind, ncol, nlay, mcica, c["irng"], c["icld"], opt, c["iceflg"], lw_in["iceflg"], lw_in["liqflg"], c["idrv"], dsw, dlw, flag), flush=True)
+        print("%3d %s ncol %4d nlay %3d mcica %d rng %d icld %d opt %d gases %d ice %d/%d liq %d idrv %d  |d| sw %.2e lw %.2e%s" % (
+            it, kind, ncol, nlay, mcica, c["irng"], c["icld"], opt, gases, c["iceflg"], lw_in["iceflg"], lw_in["liqflg"], c["idrv"], dsw, dlw, flag), flush=True)
     print("worst:", worst)
 
 
