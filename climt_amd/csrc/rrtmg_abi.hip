@@ -196,7 +196,7 @@ class HostPool {
         std::unique_lock<std::mutex> lk(m_);
         cv_.wait(lk, [this] { return !active_.empty(); });
         b = active_.back();
-        take(b, t);
+        if (!take(b, t)) continue;   // (cannot happen: a batch is in active_ only while it has slices)
       }
       run(t, *b);
     }
