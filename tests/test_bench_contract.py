@@ -77,6 +77,10 @@ def test_line_carries_issue_fraction_bound_and_the_mcica_co_headline():
     assert len(r["kernels"]) == 2 and all({"issue_frac_alone", "valu_issue_ms_per_simd", "limiter", "spectrum"} <= set(k) for k in r["kernels"])
     if r["counters_note"] is None:      # the committed counters belong to the library that ran
         assert 0.2 < r["issue_frac_serial"] < 1.0 and all(0.1 < k["issue_frac_alone"] < 1.0 for k in r["kernels"])
+    # round 6: the line says which bytes it counts -- the contract's figure beside the arrays really handed over
+    assert r["step_algorithmic_bytes_per_column"] == 43464 and r["algorithmic_bytes_shipped_per_column"] == 21864
+    assert abs(r["step_frac_on_shipped_bytes"] / r["step_frac"] - 21864 / 43464) < 1e-12 and "step_issue_frac" in r
+    assert r["hbm_rates_measured"]["write_read_mix_of_the_step"] < r["hbm_rates_measured"]["read_streaming"]
     m, rm = j["mcica"], j["roofline_mcica"]
     assert m["workload"] == "rrtmg_lw+sw_mcica_cloudy_8192col_x_60lev_per_gpu" and m["steps"] == j["steps"] and m["brackets"] >= 1
     assert m["timed_region_s"] >= 0.3 and 1.2 < m["ratio_to_clear_sky"] < 3.0 and abs(m["value"] - 8192 / (m["ms_per_step"] * 1e-3)) < 1e-6 * m["value"]
@@ -96,7 +100,8 @@ def test_one_run_measures_every_gather_mode():
         assert {"value", "ms_per_step", "brackets", "ingress_bytes_per_gpu_per_step", "ingress_GBps_per_gpu_achieved",
                 "ingress_GBps_per_gpu_needed_at_compute_rate", "slowdown_vs_none", "gather_ran"} <= set(g[m]), m
         assert g[m]["gather_ran"] == (m != "none") and g[m]["error"] is None
-    assert j["config"]["gather_mode"] in ("all", "direct") and j["config"]["communicator"].endswith("rccl")
+    assert j["config"]["gather_mode"] == "all" and j["config"]["communicator"].endswith("rccl")      # a FIXED headline mode
+    assert j["comm_selftest"] == {"all": "OK", "direct": "OK", "root": "OK", "ranks": 1}      # every mode checked on a 1 KB pattern before the brackets
     assert abs(j["value"] - g[j["config"]["gather_mode"]]["value"]) < 1e-6 * j["value"]
 
 
