@@ -237,6 +237,8 @@ def main():
                     "(default: a block-copy kernel behind the gather writes the boundary layout [array][level][column])")
     ap.add_argument("--rccl-channels", type=int, default=16, help="N>1: NCCL_MAX_NCHANNELS for the gather (each channel occupies a CU while it runs; "
                     "0 = RCCL's default; a value already in the environment wins)")
+    ap.add_argument("--sort-columns", action="store_true", help="opt-in internal column order (rrtmg_hip_set_column_sort): cloud-free columns out of cloudy tiles; "
+                    "a cloud-free column's shortwave then differs by ~1e-12 W m^-2 from the default's (docs/EXPERIMENTS.md E)")
     ap.add_argument("--contract-arrays", action="store_true", help="N=1: also hand over the band arrays SURVEY 8(d)'s contract bytes count and the synthetic columns "
                     "do not have -- zero `taucld` (LW 16 x L, SW 14 x L) and LW `tauaer` (16 x L) device arrays -- so that the kernels really read them")
     ap.add_argument("--no-comm-selftest", action="store_true", help="N>1: skip the communicator self-test (every gather mode once on a 1 KB pattern, checked on every rank, before the brackets)")
@@ -296,6 +298,8 @@ def main():
     ctx.set_constants(**CONSTANTS)
     ctx.sw_init(CPDAIR)
     ctx.lw_init(CPDAIR)
+    if a.sort_columns:
+        ctx.set_column_sort(True)
 
     def columns(ncol, nlay, cld):
         c = make_columns(ncol, nlay, cloudy=cld, seed=20260927 + rank)
@@ -702,6 +706,7 @@ def main():
                        "columns_per_gpu": N, "levels": L, "parallelism": par,
                        "communicator": (comm_note + comm_kind) if comm_kind else None,
                        "overlap": "none (serial calls)" if a.serial else "SW || LW on two HIP streams",
+                       "column_sort": bool(a.sort_columns),
                        "timed_region_s": float(np.sum(r["brackets"])) * steps * 1e-3, "brackets": len(r["brackets"]),
                        "bracket_note": "ms_per_step = median over `brackets` timed regions of exactly `steps` steps each (max over ranks per bracket)",
                        "host_sync": ("after every step" if (a.serial or a.sync_every_step or (multi and host_wait)) else

@@ -97,6 +97,7 @@ def load_library():
     lib.rrtmg_hip_solar_insolation.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp, _f64, _f64, _f64, _f64, _vp, _vp]
     lib.rrtmg_hip_kernel_ms.argtypes = [_vp, C.c_int, C.POINTER(C.c_double)]
     lib.rrtmg_hip_kernel_launches.argtypes = [_vp, C.c_int]
+    lib.rrtmg_hip_set_column_sort.argtypes = [_vp, C.c_int]
     lib.rrtmg_hip_copy_blocks.argtypes = [_vp, C.c_int, _vp, C.c_long, C.c_long, _vp, _vp, _vp]
     lib.rrtmg_hip_mcica_mask.argtypes = [_vp] + [C.c_int] * 6 + [_vp] * 3
     _lib = lib
@@ -306,6 +307,11 @@ class Context:
         self._ck(self.lib.rrtmg_hip_set_deferred(self.h, 1 if on else 0))
         self.deferred = bool(on)
         return prev
+
+    @_locked
+    def set_column_sort(self, on=True):
+        """Opt-in internal column order of device-resident calls with clouds: cloud-free columns first (rrtmg_hip_set_column_sort)."""
+        self._ck(self.lib.rrtmg_hip_set_column_sort(self.h, 1 if on else 0))
 
     @_locked
     def get_table(self, name):

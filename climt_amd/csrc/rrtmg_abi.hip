@@ -344,6 +344,7 @@ int rrtmg_hip_create(rrtmg_ctx **out, int device_ordinal) {
   rrtmg_ctx *c = new rrtmg_ctx();
   c->device = device_ordinal;
   if (const char *env = getenv("RRTMG_HIP_CHUNK_TILES")) { const int v = atoi(env); if (v > 0) { c->chunk_tiles = v; c->chunk_auto = false; } }
+  if (const char *env = getenv("RRTMG_HIP_SORT_COLUMNS")) c->sort_columns = atoi(env) != 0;
   if (const char *env = getenv("RRTMG_HIP_MAX_SCRATCH_BYTES")) { const long long v = atoll(env); if (v > 0) c->max_scratch_bytes = (size_t)v; }
   *out = c;
   if (e != hipSuccess || n <= 0)
@@ -430,6 +431,12 @@ int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on) {
   int rc = rrtmg_hip_synchronize(ctx);
   ctx->deferred = on != 0;
   return rc;
+}
+
+int rrtmg_hip_set_column_sort(rrtmg_ctx *ctx, int on) {
+  if (!ctx) return RRTMG_ERR_ARG;
+  ctx->sort_columns = on != 0;
+  return RRTMG_OK;
 }
 
 int rrtmg_hip_set_constants(rrtmg_ctx *ctx, double pi, double grav, double planck, double boltz, double clight,

@@ -107,6 +107,9 @@ struct rrtmg_ctx {
     if (big_lds[slot] < 0) big_lds[slot] = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 0;
     return big_lds[slot] > 0;
   }
+  // rrtmg_hip_set_column_sort (rrtmg_sort.h): device-resident calls with clouds run on an internal copy of their inputs, cloud-free
+  // columns first; `sorting` = this is the inner call
+  bool sort_columns = false, sorting = false;
   std::string err;
   int status = 0;
   rrtmg::Constants k{};

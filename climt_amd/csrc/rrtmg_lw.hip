@@ -17,6 +17,7 @@
 #include "rrtmg_lw_device.h"
 #include "rrtmg_lw_host.h"
 #include "rrtmg_mcica_kernels.h"
+#include "rrtmg_sort.h"
 
 namespace rrtmg {
 
@@ -188,7 +189,51 @@ int lw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob_path) {
   return RRTMG_OK;
 }
 
+// the call on an internal copy of its inputs, cloud-free columns first (rrtmg_sort.h; see sw_sorted_call)
+static int lw_sorted_call(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  hipStream_t s = ctx->deferred ? ctx->stream_lw : ctx->stream;
+  const int N = a->ncol, L = a->nlay;
+  ColumnSort cs(ctx, s, N, L, "lw.sort.");
+  if (!cs.prepare(a->cldfr)) return ctx->status;
+  rrtmg_lw_args b = *a;
+  b.ncol = cs.Np; b.shard_col0 = 0; b.shard_ncol = 0;
+  const size_t l = (size_t)L, l1 = l + 1;
+  b.play = cs.gather("play", a->play, l); b.plev = cs.gather("plev", a->plev, l1); b.tlay = cs.gather("tlay", a->tlay, l);
+  b.tlev = cs.gather("tlev", a->tlev, l1); b.tsfc = cs.gather("tsfc", a->tsfc, 1);
+  b.h2ovmr = cs.gather("h2o", a->h2ovmr, l); b.o3vmr = cs.gather("o3", a->o3vmr, l); b.co2vmr = cs.gather("co2", a->co2vmr, l);
+  b.ch4vmr = cs.gather("ch4", a->ch4vmr, l); b.n2ovmr = cs.gather("n2o", a->n2ovmr, l); b.o2vmr = cs.gather("o2", a->o2vmr, l);
+  b.cfc11vmr = cs.gather("cfc11", a->cfc11vmr, l); b.cfc12vmr = cs.gather("cfc12", a->cfc12vmr, l);
+  b.cfc22vmr = cs.gather("cfc22", a->cfc22vmr, l); b.ccl4vmr = cs.gather("ccl4", a->ccl4vmr, l);
+  b.emis = cs.gather("emis", a->emis, 16);
+  b.cldfr = cs.gather("cldfr", a->cldfr, l); b.taucld = cs.gather("taucld", a->taucld, l, 16);
+  b.cicewp = cs.gather("cicewp", a->cicewp, l); b.cliqwp = cs.gather("cliqwp", a->cliqwp, l);
+  b.reice = cs.gather("reice", a->reice, l); b.reliq = cs.gather("reliq", a->reliq, l);
+  b.tauaer = cs.gather("tauaer", a->tauaer, l * 16);
+  b.cldfmcl = cs.gather("cldfmcl", a->cldfmcl, l, kLwNGpt);
+  const bool dr = a->idrv != 0;
+  double *o[8] = {cs.out("o0", l1), cs.out("o1", l1), cs.out("o2", l), cs.out("o3", l1), cs.out("o4", l1), cs.out("o5", l),
+                  dr ? cs.out("o6", l1) : nullptr, dr ? cs.out("o7", l1) : nullptr};
+  if (!cs.ok) return ctx->status;
+  if (!a->uflx || !a->dflx || !a->hr || !a->uflxc || !a->dflxc || !a->hrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
+  if (dr && (!a->duflx_dt || !a->duflxc_dt)) return ctx->fail(RRTMG_ERR_ARG, "idrv=1 needs duflx_dt/duflxc_dt");
+  b.uflx = o[0]; b.dflx = o[1]; b.hr = o[2]; b.uflxc = o[3]; b.dflxc = o[4]; b.hrc = o[5]; b.duflx_dt = o[6]; b.duflxc_dt = o[7];
+  ctx->sorting = true;
+  rc = lw_fluxes_impl(ctx, &b);
+  ctx->sorting = false;
+  if (rc) return rc;
+  double *u[8] = {a->uflx, a->dflx, a->hr, a->uflxc, a->dflxc, a->hrc, a->duflx_dt, a->duflxc_dt};
+  for (int k = 0; k < (dr ? 8 : 6); ++k) cs.scatter(o[k], u[k], (k == 2 || k == 5) ? l : l1);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(s));
+  return RRTMG_OK;
+}
+
 int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
+  if (ctx->lw_ready && a && ctx->sort_columns && !ctx->sorting && a->memspace == 1 && a->icld != 0 && a->cldfr && a->ncol >= 128 && a->nlay > 0 && a->nlay <= 256 &&
+      !(a->mcica && a->irng != 0))
+    return lw_sorted_call(ctx, a);
   if (!ctx->lw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_lw_init has not been called");
   if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
   if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
@@ -258,7 +303,7 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
   const int hint_cloudy = (ctx->hint[1].ntile == ntile && ctx->hint[1].nlay == L) ? ctx->hint[1].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
-  chunk_tiles = ctx->plan_chunks(1, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kLwNGpt * LF_N * L * 64 * sizeof(double), "lw.w.scratch");
+  chunk_tiles = ctx->plan_chunks(1, chunk_tiles, ntile, L, (clouds && !ctx->sorting) ? hint_cloudy : -1,   /* (a sorted grid keeps the small chunks: its tiles are segregated by kind, every chunk but one is of one kind) */ (size_t)kLwNGpt * LF_N * L * 64 * sizeof(double), "lw.w.scratch");
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
   int32_t *tlist = (int32_t *)ctx->buf("lw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
   if (!tlist) ok = false;
@@ -339,7 +384,10 @@ int lw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_lw_args *a) {
       (void)hipEventRecord(ctx->chunk_event(3, ci, 1), s);
     };
     // the variant expected to find nothing goes first (see sw_fluxes_impl)
-    if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
+    // (a sorted grid -- rrtmg_sort.h -- has its cloud-free tiles first: the chunks in front of the previous call's cloudy-tile count
+    //  are expected to hold no cloudy tile)
+    const bool expect_clear = clouds && hint_cloudy >= 0 && (hint_cloudy == 0 || (ctx->sorting && t0 + nt <= ntile - hint_cloudy));
+    if (expect_clear) { cloudy_variant(); clear_variant(); }
     else { clear_variant(); if (clouds) cloudy_variant(); }
     d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[1].ncloudy : nullptr;
     hipLaunchKernelGGL(lw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);

@@ -21,6 +21,7 @@
 #include "rrtmg_sw_device.h"
 #include "rrtmg_sw_host.h"
 #include "rrtmg_mcica_kernels.h"
+#include "rrtmg_sort.h"
 
 namespace rrtmg {
 
@@ -278,7 +279,49 @@ int sw_init_impl(rrtmg_ctx *ctx, double cpdair, const char *blob_path) {
   return RRTMG_OK;
 }
 
+// the call on an internal copy of its inputs, cloud-free columns first (rrtmg_sort.h; opt-in, device pointers, kissvec or no McICA)
+static int sw_sorted_call(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
+  int rc = ctx_prepare_device(ctx);
+  if (rc) return rc;
+  const int N = a->ncol, L = a->nlay;
+  ColumnSort cs(ctx, ctx->stream, N, L, "sw.sort.");
+  if (!cs.prepare(a->cldfr)) return ctx->status;
+  rrtmg_sw_args b = *a;
+  b.ncol = cs.Np; b.shard_col0 = 0; b.shard_ncol = 0;
+  const size_t l = (size_t)L, l1 = l + 1;
+  b.play = cs.gather("play", a->play, l); b.plev = cs.gather("plev", a->plev, l1); b.tlay = cs.gather("tlay", a->tlay, l);
+  b.tlev = nullptr; b.tsfc = nullptr;   // (the shortwave reads neither)
+  b.h2ovmr = cs.gather("h2o", a->h2ovmr, l); b.o3vmr = cs.gather("o3", a->o3vmr, l); b.co2vmr = cs.gather("co2", a->co2vmr, l);
+  b.ch4vmr = cs.gather("ch4", a->ch4vmr, l); b.n2ovmr = cs.gather("n2o", a->n2ovmr, l); b.o2vmr = cs.gather("o2", a->o2vmr, l);
+  b.asdir = cs.gather("asdir", a->asdir, 1); b.asdif = cs.gather("asdif", a->asdif, 1); b.aldir = cs.gather("aldir", a->aldir, 1);
+  b.aldif = cs.gather("aldif", a->aldif, 1); b.coszen = cs.gather("coszen", a->coszen, 1);
+  b.cldfr = cs.gather("cldfr", a->cldfr, l);
+  b.taucld = cs.gather("taucld", a->taucld, l, kSwNBand); b.ssacld = cs.gather("ssacld", a->ssacld, l, kSwNBand);
+  b.asmcld = cs.gather("asmcld", a->asmcld, l, kSwNBand); b.fsfcld = cs.gather("fsfcld", a->fsfcld, l, kSwNBand);
+  b.cicewp = cs.gather("cicewp", a->cicewp, l); b.cliqwp = cs.gather("cliqwp", a->cliqwp, l);
+  b.reice = cs.gather("reice", a->reice, l); b.reliq = cs.gather("reliq", a->reliq, l);
+  b.tauaer = cs.gather("tauaer", a->tauaer, l * kSwNBand); b.ssaaer = cs.gather("ssaaer", a->ssaaer, l * kSwNBand);
+  b.asmaer = cs.gather("asmaer", a->asmaer, l * kSwNBand); b.ecaer = cs.gather("ecaer", a->ecaer, l * 6);
+  b.cldfmcl = cs.gather("cldfmcl", a->cldfmcl, l, kSwNGpt);
+  double *o[6] = {cs.out("o0", l1), cs.out("o1", l1), cs.out("o2", l), cs.out("o3", l1), cs.out("o4", l1), cs.out("o5", l)};
+  if (!cs.ok) return ctx->status;
+  if (!a->swuflx || !a->swdflx || !a->swhr || !a->swuflxc || !a->swdflxc || !a->swhrc) return ctx->fail(RRTMG_ERR_ARG, "output array is NULL");
+  b.swuflx = o[0]; b.swdflx = o[1]; b.swhr = o[2]; b.swuflxc = o[3]; b.swdflxc = o[4]; b.swhrc = o[5];
+  ctx->sorting = true;
+  rc = sw_fluxes_impl(ctx, &b);
+  ctx->sorting = false;
+  if (rc) return rc;
+  double *u[6] = {a->swuflx, a->swdflx, a->swhr, a->swuflxc, a->swdflxc, a->swhrc};
+  for (int k = 0; k < 6; ++k) cs.scatter(o[k], u[k], (k == 2 || k == 5) ? l : l1);
+  RRTMG_HIP_CHECK(ctx, hipGetLastError());
+  if (!ctx->deferred) RRTMG_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RRTMG_OK;
+}
+
 int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
+  if (ctx->sw_ready && a && ctx->sort_columns && !ctx->sorting && a->memspace == 1 && a->icld != 0 && a->cldfr && a->ncol >= 128 && a->nlay > 0 && a->nlay <= 256 &&
+      !(a->mcica && a->irng != 0))
+    return sw_sorted_call(ctx, a);
   if (!ctx->sw_ready) return ctx->fail(RRTMG_ERR_NOT_INITIALISED, "rrtmg_hip_sw_init has not been called");
   if (!a || a->ncol <= 0 || a->nlay <= 0) return ctx->fail(RRTMG_ERR_ARG, "ncol/nlay must be positive");
   if (a->nlay > 256) return ctx->fail(RRTMG_ERR_ARG, "nlay > 256 not supported (cloud-mask words)");
@@ -364,7 +407,7 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
   const int hint_cloudy = (ctx->hint[0].ntile == ntile && ctx->hint[0].nlay == L) ? ctx->hint[0].ncloudy : -1;
   int chunk_tiles = ctx->chunk_tiles;
   if (ctx->chunk_auto && L > 80 && hint_cloudy >= 0 && 10 * hint_cloudy >= 9 * ntile) chunk_tiles = 64;   // deep cloudy grid: DESIGN.md 5
-  chunk_tiles = ctx->plan_chunks(0, chunk_tiles, ntile, L, clouds ? hint_cloudy : -1, (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double), "sw.w.scratch");
+  chunk_tiles = ctx->plan_chunks(0, chunk_tiles, ntile, L, (clouds && !ctx->sorting) ? hint_cloudy : -1,   /* (a sorted grid keeps the small chunks: its tiles are segregated by kind, every chunk but one is of one kind) */ (size_t)kSwNGpt * F_NTOT * L * 64 * sizeof(double), "sw.w.scratch");
   const int ctile = ntile < chunk_tiles ? ntile : chunk_tiles;   // tiles per solve chunk
   int32_t *tlist = (int32_t *)ctx->buf("sw.w.tilelist", (size_t)(2 * ctile + 2) * 4);
   if (!tlist) ok = false;
@@ -442,7 +485,10 @@ int sw_fluxes_impl(rrtmg_ctx *ctx, const rrtmg_sw_args *a) {
       (void)hipEventRecord(ctx->chunk_event(2, ci, 1), s);
     };
     // the variant expected to find nothing goes first (order is speed only: each tile belongs to exactly one of them)
-    if (clouds && hint_cloudy == 0) { cloudy_variant(); clear_variant(); }
+    // (a sorted grid -- rrtmg_sort.h -- has its cloud-free tiles first: the chunks in front of the previous call's cloudy-tile count
+    //  are expected to hold no cloudy tile)
+    const bool expect_clear = clouds && hint_cloudy >= 0 && (hint_cloudy == 0 || (ctx->sorting && t0 + nt <= ntile - hint_cloudy));
+    if (expect_clear) { cloudy_variant(); clear_variant(); }
     else { clear_variant(); if (clouds) cloudy_variant(); }
     d.hint_out = t0 + ctile >= ntile ? (int32_t *)&ctx->hint[0].ncloudy : nullptr;
     hipLaunchKernelGGL(sw_fluxheat_kernel, dim3(nt, (L + kFluxLev) / kFluxLev), dim3(64 * (kFluxLev + 1)), 0, s, d, T, t0);

@@ -109,6 +109,17 @@ int rrtmg_hip_stream_wait(rrtmg_ctx *ctx, void *other_stream);
  * overlap on the GPU -- and the device-side error flags (the reference's `stop` conditions) are reported by the
  * next rrtmg_hip_synchronize / rrtmg_hip_set_deferred call instead.  Host-memory calls stay synchronous. */
 int rrtmg_hip_set_deferred(rrtmg_ctx *ctx, int on);
+/* OPT-IN internal column order for device-resident calls (memspace 1) with clouds (env RRTMG_HIP_SORT_COLUMNS=1 sets it at
+ * create): the call runs on an internal copy of its inputs in which the cloud-free columns come first and the cloudy ones behind,
+ * each block padded to a 64-column tile, and scatters its outputs back -- so that a cloud-free column never shares a tile
+ * (= a solve-kernel variant that computes both sky streams) with a cloudy one.  It pays where cloud-free columns are interleaved
+ * with cloudy ones more finely than 64 columns AND the grid is large (>= 32 768 columns); it costs a copy of the inputs (as much
+ * device memory again) and, on small grids, a clear-sky launch of its own.  Columns are independent, the kissvec masks are seeded
+ * per column: a cloudy column's results are the same bits as without the sort; a cloud-free column that used to sit in a cloudy
+ * tile now runs in the clear-sky variant, whose shortwave differs from the cloudy variant's clear-sky stream by ~1e-12 W m^-2 --
+ * which is why this is not the default (tile-aligned shards == the whole grid bit for bit only when a column's variant is a
+ * function of its tile).  Calls with the Mersenne twister (one positional stream) and host-pointer calls are not sorted. */
+int rrtmg_hip_set_column_sort(rrtmg_ctx *ctx, int on);
 /* Duration (ms, HIP events recorded on the stream the kernel is launched on) of a solve kernel in the last completed call:
  * which = 0 -> sw_solve_all_kernel<false> (clear-sky tiles), 1 -> lw_solve_all_kernel<false,..>, 2 -> sw_solve_cloudy_kernel,
  * 3 -> lw_solve_all_kernel<true,..>.  A call launches that kernel once per column chunk (RRTMG_HIP_CHUNK_TILES tiles of 64

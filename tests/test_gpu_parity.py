@@ -1369,3 +1369,57 @@ def test_copy_blocks_kernel_unpacks_a_three_rank_gather(gpu_ctx):
         flat = out.download()
         for k, (off, rows) in sr.boundary_offsets().items():
             assert np.array_equal(flat[off:off + rows * N].reshape(rows, N), full[k]), (mode, k)
+
+
+@pytest.mark.parametrize("mcica", [True, False])
+def test_opt_in_column_sort_keeps_cloudy_columns_bits_and_moves_cloud_free_ones_to_the_clear_sky_variant(gpu_ctx, mcica):
+    """rrtmg_hip_set_column_sort (csrc/rrtmg_sort.h): a device-resident call runs on an internal copy of its inputs,
+    cloud-free columns first.  Columns are independent and kissvec seeds per column: (i) a cloudy column gets the same BITS as
+    without the sort; (ii) a cloud-free column now runs in the clear-sky variant -- the same bits as in a call that holds
+    cloud-free columns only, and within 1e-10 W m^-2 of the unsorted call (the variants' clear-sky streams differ by ~1e-12 in
+    the shortwave: why the sort is opt-in); (iii) the result does not depend on the order the columns come in; (iv) switched off
+    again the context gives the unsorted bits."""
+    from climt_amd import _hip
+    from climt_amd._lib import LW_OUT, SW_OUT
+    from climt_amd.synthetic import make_columns, overcast
+    N, L = 1000, 40
+    c = make_columns(N, L, cloudy=True, seed=31); c.pop("lat")
+    if not mcica:
+        c = overcast(c)
+    c.update(BASE); c.update(irng=0, permuteseed=17, icld=2 if mcica else 1)
+    cloudy = (c["cldfr"] > 0).any(axis=0)
+    assert 0.15 * N < (~cloudy).sum() < 0.85 * N
+
+    def run(inp, n):
+        dev = {k: _hip.DeviceArray.from_host(v) for k, v in inp.items() if isinstance(v, np.ndarray)}
+        args = {k: v.ptr for k, v in dev.items()}
+        args.update({k: v for k, v in inp.items() if not isinstance(v, np.ndarray)}); args.update(ncol=n, nlay=L)
+        res = {}
+        for fluxes, outs in ((gpu_ctx.sw_fluxes, SW_OUT), (gpu_ctx.lw_fluxes, LW_OUT)):
+            out = {k: _hip.DeviceArray((L + lev, n)) for k, lev in outs}
+            for v in out.values():
+                v.upload(np.full(v.shape, -7.0))      # (every element must be written by the scatter)
+            fluxes(args, mcica=mcica, out={k: v.ptr for k, v in out.items()}, memspace=1)
+            res.update({k: v.download() for k, v in out.items()})
+        return res
+    plain = run(c, N)
+    try:
+        gpu_ctx.set_column_sort(True)
+        srt = run(c, N)
+        for k in plain:
+            assert np.array_equal(srt[k][:, cloudy], plain[k][:, cloudy]), k                       # (i)
+            assert maxdiff(srt[k][:, ~cloudy], plain[k][:, ~cloudy]) <= 1e-10, k                   # (ii) ...
+        only_clear = {k: (np.ascontiguousarray(v[..., ~cloudy]) if isinstance(v, np.ndarray) and v.ndim == 2 else
+                          np.ascontiguousarray(v[~cloudy]) if isinstance(v, np.ndarray) and v.shape == (N,) else v) for k, v in c.items()}
+        clr = run(only_clear, int((~cloudy).sum()))
+        for k in plain:
+            assert np.array_equal(srt[k][:, ~cloudy], clr[k]), k                                   # ... (ii)
+        perm = np.random.default_rng(5).permutation(N)
+        shuffled = {k: (np.ascontiguousarray(v[..., perm]) if isinstance(v, np.ndarray) and (v.ndim == 2 or v.shape == (N,)) else v) for k, v in c.items()}
+        sh = run(shuffled, N)
+        for k in plain:
+            assert np.array_equal(sh[k], srt[k][:, perm]), k                                       # (iii)
+    finally:
+        gpu_ctx.set_column_sort(False)
+    again = run(c, N)
+    assert all(np.array_equal(again[k], plain[k]) for k in plain)                                  # (iv)
