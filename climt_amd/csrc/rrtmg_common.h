@@ -48,17 +48,17 @@ RRTMG_HD double qdiv(double a, double b) {
 #endif
 }
 RRTMG_HD double qrcp(double b) { return qdiv(1.0, b); }
-// Square root of a normal, strictly positive number (the two-stream k = sqrt(gamma1^2 - gamma2^2) > 0): v_rsq_f64, one
-// coupled Goldschmidt iteration and one residual correction -- 8 instructions instead of the 18 of the IEEE expansion
-// (range scaling, class fix-up, second correction).  Measured <= 1 ulp (tools/micro/rsq_accuracy.hip).
+// Square root of a normal, strictly positive number (the two-stream k = sqrt(gamma1^2 - gamma2^2) > 0): v_rsq_f64 and one
+// coupled Goldschmidt iteration -- 4 instructions behind the rsq instead of the 18 of the IEEE expansion (range scaling, class
+// fix-up, two corrections).  Measured <= 4.2e-15 relative (tools/micro/rsq_accuracy.hip: x*rsq 5.2e-8, + the iteration 4.1e-15;
+// the residual correction that rounds 2-5 had behind it gives sqrt() itself and costs three more instructions per layer operator
+// in a kernel whose time follows its VALU instruction count: docs/EXPERIMENTS.md E).  The accuracy class of qdiv; the operand
+// itself carries the reference's cancellation noise of ~1e-16 / (1 - w).
 RRTMG_HD double qsqrt(double a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const double y = __builtin_amdgcn_rsq(a);
-  double g = a * y, h = 0.5 * y;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  return __builtin_fma(__builtin_fma(-g, g, a), h, g);
+  const double g = a * y, h = 0.5 * y;
+  return __builtin_fma(g, __builtin_fma(-h, g, 0.5), g);
 #else
   return sqrt(a);
 #endif

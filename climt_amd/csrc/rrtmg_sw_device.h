@@ -525,6 +525,16 @@ RRTMG_HD double sw_exp_lookup(const double *exp_tbl, double x) {
   return exp_tbl[itind];
 }
 
+// min(x, 500), the clamp of reftra's exponents (rrtmg_sw_reftra.f90:198,262-263): ONE v_min_f64 on the device instead of a compare and
+// two selects (x is the result of a multiplication, never a signalling NaN; a NaN -- the reference keeps it -- becomes 500)
+RRTMG_HD double cap500(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_fmin(x, 500.0);
+#else
+  return x > 500.0 ? 500.0 : x;
+#endif
+}
+
 // direct-beam transmittance of a layer (rrtmg_sw_spcvrt.f90:562-574)
 // rmu0 = 1/prmu0, formed once per column: tau/prmu0 is evaluated as tau*rmu0 (<= 1 ulp apart)
 RRTMG_HD double sw_dbt(const double *exp_tbl, double tau, double rmu0) {
@@ -564,7 +574,7 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     const double zgt = zgamma1 * zto1;
     const double zeu = zto1 * rmuz;
     double ze1 = zeu;
-    if (ze1 > 500.0) ze1 = 500.0;
+    ze1 = cap500(ze1);
     double ze2;
     if (ze1 <= od_lo) ze2 = 1.0 - ze1 + 0.5 * ze1 * ze1; else ze2 = sw_exp_lookup(exp_tbl, ze1);
     pdbt = zeu > 500.0 ? sw_exp_lookup(exp_tbl, zeu) : ze2;
@@ -590,9 +600,9 @@ RRTMG_HD void sw_reftra(const double *exp_tbl, double zg, double prmuz, double r
     const double zt1 = zrp1 * (za1 + zrk * zgamma4);
     const double zt2 = zrm1 * (za1 - zrk * zgamma4);
     const double zt3 = zrk2 * (zgamma4 + za1 * prmuz);
-    double ze1 = zrk * zto1; if (ze1 > 500.0) ze1 = 500.0;
+    const double ze1 = cap500(zrk * zto1);
     const double zeu = zto1 * rmuz;
-    double ze2 = zeu; if (ze2 > 500.0) ze2 = 500.0;
+    const double ze2 = cap500(zeu);
     double zem1, zem2;
     if (ze1 <= od_lo) zem1 = 1.0 - ze1 + 0.5 * ze1 * ze1; else zem1 = sw_exp_lookup(exp_tbl, ze1);
     if (ze2 <= od_lo) zem2 = 1.0 - ze2 + 0.5 * ze2 * ze2; else zem2 = sw_exp_lookup(exp_tbl, ze2);
@@ -656,9 +666,15 @@ struct SwSpec { int js; double fs; double speccomb; };
 RRTMG_HD SwSpec sw_specparm(double colx, double coly, double strrat, double mult) {
   SwSpec r;
   r.speccomb = colx + strrat * coly;
-  double specparm = colx / r.speccomb;
   const double oneminus = 1.0 - 1.e-6;
+#if defined(__HIP_DEVICE_COMPILE__)
+  // the quick quotient and ONE v_min_f64: a last-place difference in specparm can move js across an integer only together with
+  // fs across 0 / 1, and the interpolation between rows js, js + 1 is continuous there (unlike a nearest-entry table lookup)
+  const double specparm = __builtin_fmin(qdiv(colx, r.speccomb), oneminus);
+#else
+  double specparm = colx / r.speccomb;
   if (specparm >= oneminus) specparm = oneminus;
+#endif
   const double specmult = mult * specparm;
   r.js = 1 + (int)specmult;
   r.fs = specmult - (double)(int)specmult;   // mod(specmult, 1)

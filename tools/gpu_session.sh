@@ -78,7 +78,8 @@ except Exception as e:
         for P in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES" \
                  "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
                  "TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum" \
-                 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS"; do
+                 "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS" \
+                 "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQ_IFETCH SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_BRANCH SQ_INSTS_SMEM"; do
           i=$((i+1)); out=$O/pmcab_$i; rm -rf $out
           RRTMG_HIP_LIB=$L timeout 300 rocprofv3 --kernel-trace --pmc $P -d $out -- python bench.py --no-cpu-baseline --no-extra --no-mcica --serial --steps 3 --warmup 1 --min-seconds 0 > $out.log 2>&1
           f=$(find $out -name "*.db" | head -1); [ -n "$f" ] && python tools/rocpd_pmc.py $f ${PMC_FILTER:-lw_solve_all_kernel} | sed "s/^/$lib /" >> $O/${R}_pmcab.txt; rm -rf $out
