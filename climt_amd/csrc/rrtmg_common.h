@@ -36,8 +36,10 @@ RRTMG_HD void report_error(int *flag, int code) {
 // (relative error <= 2.2e-15, i.e. ~20 ulp; 4 instructions) instead of the 11-instruction IEEE sequence (div_scale x2,
 // rcp, 6 fma, div_fmas, div_fixup) -- divisions were ~60 % of the VALU instructions of the solve kernels, which are
 // VALU-issue bound.  Fluxes move by ~1e-10 W m-2 (bar: 1e-2); a second step would give 1 ulp.  Operands here are
-// O(1e-20..1e20) and never zero/inf/denormal.  NOT used where an integer selects a table ROW (specparm -> js):
-// those keep the correctly rounded `/`.  On the host (tests/emu) it is the plain division.
+// O(1e-20..1e20) and never zero/inf/denormal.  NOT used for the quotient of a NEAREST-ENTRY table index in the longwave (LW_TDIV:
+// a last-place difference there reads a neighbouring entry 1e-4 away); the shortwave's species parameter (sw_specparm: specparm ->
+// js, fs) takes it since round 6 -- between rows js and js + 1 the interpolation is continuous, the integer can only move together
+// with fs across 0 / 1 -- the longwave's (lw_spec) keeps the correctly rounded `/`.  On the host (tests/emu) it is the plain division.
 RRTMG_HD double qdiv(double a, double b) {
 #if defined(__HIP_DEVICE_COMPILE__)
   double r = __builtin_amdgcn_rcp(b);                    // measured on gfx950: relative error <= 4.6e-8
