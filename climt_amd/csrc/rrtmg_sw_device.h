@@ -1014,9 +1014,6 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   c.prmu0 = d.cossza[col];
   c.rmu0 = 1.0 / c.prmu0;
   c.laytrop = d.laytrop[col];
-  double zinc[G];
-#pragma unroll
-  for (int g = 0; g < G; ++g) zinc[g] = sw_incflux<BAND>(d, T, col, ig0 + g, c.prmu0);
   // albedo by band: bands 1-9 and 14 near-IR, 10-13 UV/vis (rrtmg_sw_rad.nomcica.f90:648-659)
   const bool vis = (c.b >= 9 && c.b <= 12);
   const double albp = vis ? d.asdir[col] : d.aldir[col];
@@ -1075,7 +1072,21 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
   // ---- sweep 2: top -> bottom; downward recurrence + fluxes at every interface (:142-169) -------------
   double tdnc[G], rdndc[G], tdbtc[G], tdn[G], rdnd[G], tdbt[G];
 #pragma unroll
-  for (int g = 0; g < G; ++g) { tdnc[g] = 1.0; rdndc[g] = 0.0; tdbtc[g] = 1.0; tdn[g] = 1.0; rdnd[g] = 0.0; tdbt[g] = 1.0; }
+  for (int g = 0; g < G; ++g) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the downward recurrence and the flux formula are linear in (tdn, tdbt): starting them at the g-point's incoming flux instead
+    // of 1 gives the fluxes already weighted (rrtmg_sw_spcvrt.f90:623-627: zincflx * zfd) -- the weights need no registers through
+    // the sweep (8 of the clear-sky kernel's 128), at last-place differences in the products
+    const double zinc = sw_incflux<BAND>(d, T, col, ig0 + g, c.prmu0);
+#else
+    const double zinc = 1.0;
+#endif
+    tdnc[g] = zinc; rdndc[g] = 0.0; tdbtc[g] = zinc; tdn[g] = zinc; rdnd[g] = 0.0; tdbt[g] = zinc;
+  }
+#if !defined(__HIP_DEVICE_COMPILE__)
+  double zinc[G];   // host: the reference's order, the weights applied to the unit fluxes
+  for (int g = 0; g < G; ++g) zinc[g] = sw_incflux<BAND>(d, T, col, ig0 + g, c.prmu0);
+#endif
   for (int lev = L; lev >= 0; --lev) {
     double sfu[G / 2], sfd[G / 2], scu[G / 2], scd[G / 2];
 #pragma unroll
@@ -1102,7 +1113,11 @@ RRTMG_HD void sw_solve_thread(const SwDev &d, const SwTab &T, const double *exp_
         fd = tdbt[g] + (tdn[g] - tdbt[g] + tdbt[g] * r * rdnd[g]) * zr;
       }
       const int h = g >> 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+      sfu[h] = sfu[h] + fu; sfd[h] = sfd[h] + fd; scu[h] = scu[h] + cu; scd[h] = scd[h] + cd;
+#else
       sfu[h] = sfu[h] + zinc[g] * fu; sfd[h] = sfd[h] + zinc[g] * fd; scu[h] = scu[h] + zinc[g] * cu; scd[h] = scd[h] + zinc[g] * cd;
+#endif
     }
     if constexpr (CLD && G == 4) {
       // one slot per chunk: the two pairs' sums added here (pair0 + pair1, the association the flux sums have had since round 1)
