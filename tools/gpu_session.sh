@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun session (development tool): tools/gpu_session.sh <tag> <sections...>
-#   sections: tests smoke bench dist sizes ab:<lib1,lib2,...> phases prof pmc pmclarge sq
+#   sections: tests smoke bench dist sizes ab:<lib1,lib2,...> phases prof profsizes pmc pmclarge sq
 # Everything lands under gpurun_out/<tag>_*; the summaries to be judged are copied into profiles/ afterwards.
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 export RRTMG_HIP_ALLOW_SYNTHETIC_LW=1
@@ -101,6 +101,15 @@ except Exception as e:
           stats $out $O/${R}_bench_${mode}_${variant}_kernel_stats.txt
         done
       done; head -12 $O/${R}_bench_clear_serial_kernel_stats.txt ;;
+    profsizes)
+      # kernel stats of the large configurations (BASELINE configs 4 and 5 at shard size, 131 072 clear-sky columns)
+      for spec in "config4:--config 4 --steps 12" "config5:--config 5 --steps 3" "clear131072:--columns 131072 --steps 6"; do
+        tag=${spec%%:*}; args=${spec#*:}
+        out=$O/prof_$tag; rm -rf $out
+        timeout 400 rocprofv3 --kernel-trace --stats -d $out -- python bench.py --no-cpu-baseline --no-extra --no-mcica --warmup 2 --min-seconds 0 $args > $out.log 2>&1
+        grep "^{" $out.log | tail -1 > $O/${R}_bench_${tag}_profiled.json
+        stats $out $O/${R}_bench_${tag}_kernel_stats.txt; head -8 $O/${R}_bench_${tag}_kernel_stats.txt
+      done ;;
     pmc|pmclarge)
       n=8192; tag=""; [ $sec = pmclarge ] && { n=131072; tag="_131072"; }
       for mode in clear cloudy; do
