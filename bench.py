@@ -72,7 +72,7 @@ FP64_PEAK = 78.6e12
 N_SIMD, CLOCK_HZ = 1024, 2.4e9      # 256 CUs x 4 SIMDs; peak engine clock (MI355X_MICROARCH.md): the VALU issue floor below is per SIMD
 # what holds each solve kernel (measured: docs/EXPERIMENTS.md B-D), printed as roofline.limiter
 LIMITER = {"sw": "valu-issue (FP64): a workgroup is alone on its CU and its 4 waves per SIMD issue VALU instructions for ~63 % of its lifetime; the kernel's time follows its VALU instruction count as long as nothing spills; its scratch slab, partial planes and prep rows cost it 0-3 % (clean ablations, round 6: docs/EXPERIMENTS.md E)",
-         "lw": "latency of a layer's four dependent memory trips at 2 waves per SIMD (VALU issue 27 %; a third wave per SIMD adds nothing: round 6) + the bytes it WRITES: the 1.1 GB of scratch-slab stores per launch cost 17 % of the kernel and 8.5 % of the step, the reads nothing (clean ablations: profiles/r06_ab_clean_ablations.txt)"}
+         "lw": "latency of a layer's four dependent memory trips at 2 waves per SIMD (VALU issue 27 %; a third wave per SIMD adds nothing: round 6) + its scratch-slab STORES (1.1 GB per launch) in the same in-order vector-memory path: they cost 17 % of the kernel and 8.5 % of the step, the reads nothing; held in the L2 instead of HBM they still cost 12 % (clean ablations: profiles/r06_ab_clean_ablations.txt)"}
 FLAGS = dict(icld=1, iaer=0, dyofyr=1, scon=1367.0, isolvar=0, inflg=2, iceflg=1, liqflg=1, irng=0, permuteseed=684)
 
 
